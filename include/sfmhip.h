@@ -1,0 +1,231 @@
+/*
+ * sfmhip.h -- C-ABI of libsfmhip.so: the MI355X (gfx950) implementation of the
+ * matching -> triangulation -> bundle-adjustment hot path of CaptainEven/SFM_OpenCV.
+ *
+ * The reference has no FFI/plugin interface; its boundary is the set of free
+ * functions in OpenCV_SFM/NViewReconstuct.cpp ("NView" below). Every entry point
+ * here names the reference call it replaces.  Plain pointers and sizes only: no
+ * OpenCV, torch or HIP types cross this boundary (streams travel as void*).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = SFMHIP_E_*; nothing throws or exits
+ *     (reference convention: int 0/-1 + "[Err]:" prints, NView:1122-1126, 301-306).
+ *   - "host" entry points take host pointers, run H2D -> kernels -> D2H and return after a
+ *     stream sync (reference calls are synchronous, NView:1369/1441/1491).
+ *   - "_dev" entry points take device pointers (HBM-resident inputs/outputs) and enqueue on the
+ *     context's stream without synchronising; the caller owns all buffers.
+ *   - one context per process per GPU (one process per GPU; multi-GPU = N processes + an
+ *     all-reduce hook, see sfmhip_ba_set_allreduce).
+ */
+#ifndef SFMHIP_H_
+#define SFMHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFMHIP_OK          0
+#define SFMHIP_E_ARG      (-1)  /* bad argument (mirrors the reference's -1) */
+#define SFMHIP_E_HIP      (-2)  /* HIP runtime error (see sfmhip_last_error) */
+#define SFMHIP_E_COMM     (-3)  /* all-reduce hook failed */
+#define SFMHIP_E_NUMERIC  (-4)  /* non-finite value / factorisation failure */
+#define SFMHIP_E_NODEVICE (-5)  /* no usable gfx950 device: the product path never falls back to CPU */
+
+/* ---- POD mirrors of the OpenCV types that cross the reference's boundary ---- */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } sfm_dmatch;      /* cv::DMatch, 16 B */
+typedef struct { float x, y; } sfm_point2f;                                              /* cv::Point2f */
+typedef struct { double x, y, z; } sfm_point3d;                                          /* cv::Point3d */
+typedef struct { float x, y; float size, angle, response; int32_t octave, class_id; } sfm_keypoint; /* cv::KeyPoint, 28 B */
+typedef struct { uint8_t b, g, r; } sfm_vec3b;                                           /* cv::Vec3b (BGR as sampled, NView:838) */
+
+typedef struct sfmhip_ctx sfmhip_ctx;
+typedef struct sfmhip_descset sfmhip_descset;   /* one image's descriptors, prepared and HBM-resident */
+typedef struct sfmhip_ba sfmhip_ba;             /* one bundle-adjustment problem, HBM-resident */
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int  sfmhip_create(int device, sfmhip_ctx** out);
+void sfmhip_destroy(sfmhip_ctx* ctx);
+/* enqueue on an external stream (e.g. torch's current stream); NULL = the context's own stream */
+int  sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream);
+int  sfmhip_synchronize(sfmhip_ctx* ctx);
+const char* sfmhip_last_error(sfmhip_ctx* ctx);
+const char* sfmhip_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* matching: replaces cv::BFMatcher(norm).knnMatch(query, train, knn, 2) + the ratio tail of   */
+/* match_features (NView:873-913; L2/SIFT twin TwoViewReconstruct.cpp:156-194)                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* flags reported by sfmhip_descset_info */
+#define SFMHIP_DESC_L2_F32      1   /* NORM_L2 on CV_32F rows (SIFT) */
+#define SFMHIP_DESC_HAMMING2_U8 2   /* NORM_HAMMING2 on CV_8U rows (AKAZE MLDB, 61 B) */
+
+/* Prepare one image's descriptor matrix (rows x dim, row stride ld elements).
+ * L2: a device pass checks whether every value is an integer in [0,255] (OpenCV SIFT output is);
+ *     if so the set also carries a biased int8 copy + squared norms and is matched on the int8
+ *     MFMA path, which is exact; otherwise only the exact fp32 direct-difference path is used.
+ * host variants copy the rows to HBM first. */
+int sfmhip_descset_create_l2_host(sfmhip_ctx*, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out);
+int sfmhip_descset_create_l2_dev (sfmhip_ctx*, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out);
+int sfmhip_descset_create_hamming2_host(sfmhip_ctx*, const uint8_t* desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
+int sfmhip_descset_create_hamming2_dev (sfmhip_ctx*, const uint8_t* d_desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
+void sfmhip_descset_destroy(sfmhip_descset*);
+/* kind = SFMHIP_DESC_*; exact_u8 = 1 when the int8 MFMA path is usable (synchronises) */
+int sfmhip_descset_info(sfmhip_descset*, int* kind, int* rows, int* dim, int* exact_u8);
+
+/* kNN-2 of every query row against all train rows (cv::batchDistance semantics [3P]: ascending
+ * distance, ties -> lower train index, missing neighbours idx=-1 / dist=FLT_MAX or INT_MAX).
+ * idx2: rows_q x 2 int32.  dist2: rows_q x 2 float (L2: sqrtf of the squared distance;
+ * Hamming2: the integer distance converted to float, as BFMatcher::knnMatchImpl does).
+ * force_path: 0 = auto, 1 = exact fp32 direct-difference path, 2 = int8 MFMA path (E_ARG if unusable). */
+int sfmhip_knn2_dev(sfmhip_ctx*, const sfmhip_descset* query, const sfmhip_descset* train,
+                    int32_t* d_idx2, float* d_dist2, int force_path);
+
+/* host-buffer one-shots (what a reference-side binding of BFMatcher::knnMatch(k=2) calls) */
+int sfmhip_knn2_l2_f32(sfmhip_ctx*, const float* q, int nq, const float* t, int nt, int dim,
+                       size_t ldq, size_t ldt, int32_t* idx2, float* dist2);
+int sfmhip_knn2_hamming2_u8(sfmhip_ctx*, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
+                            size_t ldq, size_t ldt, int32_t* idx2, float* dist2);
+
+/* The ratio tail of match_features, NView:880-908, in the reference's arithmetic:
+ * pass 1: min_dist = min d0 over rows with !(d0 > ratio*d1) (double compare, NView:884);
+ * pass 2: keep row iff !(d0 > ratio*d1 || d0 > mult*max(min_dist, floor_)) (float gate, NView:900-901).
+ * Pure host C (no device).  out must hold nq entries.  Rows with fewer than 2 neighbours are
+ * dropped (the reference would read out of bounds). */
+int sfmhip_ratio_filter(const int32_t* idx2, const float* dist2, int nq,
+                        double ratio, float floor_, float mult, sfm_dmatch* out, int* n_out);
+
+/* match_features (NView:873): kNN-2 + ratio tail, one pair, host buffers. */
+int sfmhip_match_features_l2(sfmhip_ctx*, const float* q, int nq, const float* t, int nt, int dim,
+                             size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out);
+int sfmhip_match_features_hamming2(sfmhip_ctx*, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
+                                   size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out);
+
+/* match_features_for_all (NView:850-871) generalised to a pair list: pairs[2*p] = query image,
+ * pairs[2*p+1] = train image (reference: (i, i+1)).  All pairs are matched in batched launches;
+ * the ratio tail and the ordered compaction run on the device (fp64 compare = the host's).
+ * d_matches: n_pairs x max_per_pair sfm_dmatch (device), d_counts: n_pairs int32 (device).
+ * max_per_pair must be >= the largest query row count. Enqueues only. */
+int sfmhip_match_pairs_dev(sfmhip_ctx*, sfmhip_descset* const* sets, int n_sets,
+                           const int32_t* pairs, int n_pairs,
+                           double ratio, float floor_, float mult,
+                           sfm_dmatch* d_matches, int max_per_pair, int32_t* d_counts);
+/* host-output form: matches_out[n_pairs*max_per_pair], counts_out[n_pairs]; synchronises. */
+int sfmhip_match_pairs(sfmhip_ctx*, sfmhip_descset* const* sets, int n_sets,
+                       const int32_t* pairs, int n_pairs,
+                       double ratio, float floor_, float mult,
+                       sfm_dmatch* matches_out, int max_per_pair, int32_t* counts_out);
+
+/* Materialised L2 distance matrix dist[i*ld + j] = sqrtf(sum_k (q[i,k]-t[j,k])^2), rows_q x rows_t
+ * float32 in HBM (the "10k x 10k SIFT distance GEMM" roofline case; what cv::batchDistance(K=0)
+ * would return [3P]). Enqueues only. */
+int sfmhip_l2_distance_matrix_dev(sfmhip_ctx*, const sfmhip_descset* query, const sfmhip_descset* train,
+                                  float* d_dist, size_t ld, int force_path);
+
+/* ------------------------------------------------------------------------------------------ */
+/* triangulation: replaces cv::triangulatePoints + the float32 de-homogenisation loop of       */
+/* reconstruct (NView:1147-1156).  P1,P2: row-major 3x4 float32 (= float(K)*[float(R)|float(T)],*/
+/* NView:1129-1143, built by the caller/wrapper).  xy1,xy2: n x 2 float32.                      */
+/* xyzw: 4 x n float32 exactly like pts4d (row-major, may be NULL); xyz: n x 3 double holding   */
+/* float32-exact values (Point3f -> Point3d, NView:1155; may be NULL).                          */
+/* ------------------------------------------------------------------------------------------ */
+int sfmhip_triangulate2_f32(sfmhip_ctx*, const float P1[12], const float P2[12],
+                            const float* xy1, const float* xy2, int n, float* xyzw, double* xyz);
+int sfmhip_triangulate2_f32_dev(sfmhip_ctx*, const float P1[12], const float P2[12],
+                                const float* d_xy1, const float* d_xy2, int n, float* d_xyzw, double* d_xyz);
+/* fused get_matched_points (NView:989-1003) + triangulation: points are gathered on the device
+ * from keypoint arrays through the match list. kp1/kp2: sfm_keypoint arrays (device). */
+int sfmhip_triangulate2_matches_dev(sfmhip_ctx*, const float P1[12], const float P2[12],
+                                    const sfm_keypoint* d_kp1, const sfm_keypoint* d_kp2,
+                                    const sfm_dmatch* d_matches, int n, float* d_xyzw, double* d_xyz);
+
+/* ------------------------------------------------------------------------------------------ */
+/* bundle adjustment: replaces bundle_adjustment (NView:1162-1244) = ceres::Solve on            */
+/* AutoDiffCostFunction<ReprojectCost,2,4,6,3> (NView:142-184) + HuberLoss(4) + SPARSE_SCHUR.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int    max_num_iterations;          /* 50   (Ceres default [3P]) */
+    double initial_trust_region_radius; /* 1e4  */
+    double max_trust_region_radius;     /* 1e16 */
+    double min_trust_region_radius;     /* 1e-32 */
+    double min_relative_decrease;       /* 1e-3 */
+    double min_lm_diagonal;             /* 1e-6 */
+    double max_lm_diagonal;             /* 1e32 */
+    double function_tolerance;          /* 1e-6 */
+    double gradient_tolerance;          /* 1e-10 */
+    double parameter_tolerance;         /* 1e-8 */
+    double huber_delta;                 /* 4.0  (NView:1184); <= 0 disables the loss */
+    int    jacobi_scaling;              /* 1 */
+    int    fix_first_camera;            /* 1    (NView:1178) */
+    int    fix_intrinsics;              /* 0    (NView:1181: free, shared) */
+    int    verbose;                     /* 0    (NView:1216-1217) */
+} sfm_ba_options;
+
+#define SFMHIP_BA_CONVERGENCE     0
+#define SFMHIP_BA_NO_CONVERGENCE  1
+#define SFMHIP_BA_FAILURE         2
+
+typedef struct {
+    int    termination;      /* SFMHIP_BA_* */
+    int    iterations;       /* LM iterations taken (excluding iteration 0), successful + unsuccessful */
+    int    successful_steps;
+    int    num_residuals;    /* 2 * n_obs (NView:1236) */
+    double initial_cost;     /* 1/2 sum rho(|r|^2) (NView:1237) */
+    double final_cost;
+    double final_radius;
+    double final_gradient_max_norm;
+    double total_time_s;
+} sfm_ba_summary;
+
+void sfmhip_ba_default_options(sfm_ba_options* o);
+
+/* One-shot, in place on caller memory like the reference (NView:1174,1181,1209):
+ * intrinsic4 = (fx,fy,cx,cy); ext6 = n_cam x 6 (angle-axis, t); pts = n_pt x 3;
+ * observation k: camera obs_cam[k] sees point obs_pt[k] at obs_uv[2k..2k+1] (double, NView:1199). */
+int sfmhip_ba_solve(sfmhip_ctx*, double* intrinsic4, double* ext6, int n_cam, double* pts, int n_pt,
+                    const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
+                    const sfm_ba_options* opts, sfm_ba_summary* summary);
+
+/* Resident form (bench, multi-GPU): create uploads + builds the per-point / per-camera orderings. */
+int  sfmhip_ba_create(sfmhip_ctx*, const double* intrinsic4, const double* ext6, int n_cam,
+                      const double* pts, int n_pt,
+                      const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
+                      const sfm_ba_options* opts, sfmhip_ba** out);
+void sfmhip_ba_destroy(sfmhip_ba*);
+/* Multi-GPU: this rank holds a shard of the points (all their observations) and a replica of the
+ * cameras/intrinsics.  The hook must sum `count` doubles at device pointer `d_buf` in place over all
+ * ranks, ordered on `hip_stream`; return 0 on success.  (RCCL: ncclAllReduce(d_buf,d_buf,count,
+ * ncclDouble,ncclSum,comm,stream); torch.distributed: dist.all_reduce on a tensor view.) */
+typedef int (*sfmhip_allreduce_fn)(void* user, void* d_buf, size_t count, void* hip_stream);
+int  sfmhip_ba_set_allreduce(sfmhip_ba*, sfmhip_allreduce_fn fn, void* user);
+/* run the LM loop to termination */
+int  sfmhip_ba_run(sfmhip_ba*, sfm_ba_summary* summary);
+/* run exactly n_iter LM iterations (tolerance checks disabled); state carries over between calls */
+int  sfmhip_ba_iterate(sfmhip_ba*, int n_iter, sfm_ba_summary* summary);
+/* restore the parameters given at create and reset the LM state */
+int  sfmhip_ba_reset(sfmhip_ba*);
+int  sfmhip_ba_get_params(sfmhip_ba*, double* intrinsic4, double* ext6, double* pts);
+/* Test/diagnostic: linearise at the current parameters with trust-region radius `radius` and copy
+ * out the reduced camera system (order n = 6*(n_cam - fixed) + 4*(!fix_intrinsics); S row-major n x n,
+ * lower triangle valid; rhs n) after the all-reduce.  Either pointer may be NULL. */
+int  sfmhip_ba_reduced_system(sfmhip_ba*, double radius, double* S, double* rhs, int* n, double* cost);
+/* average device time (ms) of the phases of the last sfmhip_ba_iterate call, measured with HIP events on
+ * the context's stream: [0]=linearise+Schur build, [1]=reduced solve, [2]=back-substitution+cost, [3]=total */
+int  sfmhip_ba_phase_ms(sfmhip_ba*, double out_ms[4]);
+
+/* ------------------------------------------------------------------------------------------ */
+/* "next" row 8f-1: normals for the .ply writer (estimate_normals NView:551-599 + PCAFitPlane   */
+/* 601-690): brute-force kNN-K (self excluded) + 3x3 PCA, smallest-eigenvalue vector, flipped   */
+/* so that n.mean <= 0, normalised.  pts: n x 3 double; normals: n x 3 double.                  */
+/* ------------------------------------------------------------------------------------------ */
+int sfmhip_estimate_normals(sfmhip_ctx*, const double* pts, int n, int K, double* normals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMHIP_H_ */

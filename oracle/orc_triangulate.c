@@ -1,0 +1,99 @@
+/*
+ * oracle/orc_triangulate.c -- CPU restatement of reconstruct() (TEST INFRASTRUCTURE, see orc.h).
+ *
+ * Follows NView:1117-1159.  cv::triangulatePoints (OpenCV 4.4.0 calib3d, not in /root/reference)
+ * restated from its published source [3P]: per correspondence build the 4x4 system in double
+ *     A[2j+0][k] = x_j * P_j[2][k] - P_j[0][k]
+ *     A[2j+1][k] = y_j * P_j[2][k] - P_j[1][k]        j = 0,1 (views), k = 0..3
+ * from float32 points and float32 3x4 projections, cv::SVD::compute(A, w, u, vt), output the last
+ * row of vt (right singular vector of the smallest singular value) cast to the point type (float32).
+ * The SVD here is a one-sided (Hestenes) Jacobi in double; OpenCV's JacobiSVD differs in sweep
+ * order, so the null vector agrees to ~1e-15*cond and in sign only up to +-1 (the sign cancels in
+ * the division by w, NView:1154).
+ * De-homogenisation NView:1153-1155: `Mat_<float> /= w` is convertTo(alpha = 1./w) [3P], i.e. a
+ * float multiply by (float)(1.0/(double)w); then Point3f -> Point3d.
+ * parity unpinned; cross-checked vs numpy.linalg.svd in tests/.
+ */
+#include "orc.h"
+#include <math.h>
+
+/* null vector (unit 2-norm) of a 4x4 matrix: right singular vector of the smallest singular value */
+static void null_vector4(const double Ain[16], double v[4])
+{
+    double A[4][4], V[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { A[i][j] = Ain[4 * i + j]; V[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < 4; ++i) { a += A[i][p] * A[i][p]; b += A[i][q] * A[i][q]; g += A[i][p] * A[i][q]; }
+                if (fabs(g) <= 1e-16 * sqrt(a * b) || g == 0.0) continue;
+                rotated = 1;
+                double zeta = (b - a) / (2.0 * g);
+                double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int i = 0; i < 4; ++i) {
+                    double x = A[i][p], y = A[i][q];
+                    A[i][p] = c * x - s * y; A[i][q] = s * x + c * y;
+                    x = V[i][p]; y = V[i][q];
+                    V[i][p] = c * x - s * y; V[i][q] = s * x + c * y;
+                }
+            }
+        if (!rotated) break;
+    }
+    int m = 0; double best = INFINITY;
+    for (int j = 0; j < 4; ++j) {
+        double nn = 0;
+        for (int i = 0; i < 4; ++i) nn += A[i][j] * A[i][j];
+        if (nn < best) { best = nn; m = j; }
+    }
+    for (int i = 0; i < 4; ++i) v[i] = V[i][m];
+}
+
+void orc_triangulate2(const float P1[12], const float P2[12], const float* xy1, const float* xy2,
+                      int n, float* xyzw, double* xyz)
+{
+    const float* P[2] = { P1, P2 };
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double A[16], v[4];
+        const float* pt[2] = { xy1 + 2 * i, xy2 + 2 * i };
+        for (int j = 0; j < 2; ++j) {
+            double x = pt[j][0], y = pt[j][1];
+            for (int k = 0; k < 4; ++k) {
+                A[4 * (2 * j) + k]     = x * (double)P[j][8 + k] - (double)P[j][k];
+                A[4 * (2 * j + 1) + k] = y * (double)P[j][8 + k] - (double)P[j][4 + k];
+            }
+        }
+        null_vector4(A, v);
+        float h[4] = { (float)v[0], (float)v[1], (float)v[2], (float)v[3] };
+        if (xyzw) for (int k = 0; k < 4; ++k) xyzw[(size_t)k * n + i] = h[k];
+        if (xyz) {
+            float inv = (float)(1.0 / (double)h[3]);
+            xyz[3 * i + 0] = (double)(h[0] * inv);
+            xyz[3 * i + 1] = (double)(h[1] * inv);
+            xyz[3 * i + 2] = (double)(h[2] * inv);
+        }
+    }
+}
+
+/* NView:1129-1143: R, T, K converted to CV_32F, then proj = fK * [R|T] as a float32 cv::Mat product.
+ * [3P] cv::gemm on CV_32F accumulates each 3-term dot product in double and rounds once to float
+ * (GEMMSingleMul<float,double>), restated here. */
+void orc_projection_matrix(const double K[9], const double R[9], const double T[3], float P[12])
+{
+    float fK[9], RT[12];
+    for (int i = 0; i < 9; ++i) fK[i] = (float)K[i];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) RT[4 * r + c] = (float)R[3 * r + c];
+        RT[4 * r + 3] = (float)T[r];
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += (double)fK[3 * r + k] * (double)RT[4 * k + c];
+            P[4 * r + c] = (float)s;
+        }
+}
