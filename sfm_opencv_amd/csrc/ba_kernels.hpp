@@ -1,0 +1,731 @@
+// ba_kernels.hpp -- device code of the bundle-adjustment path (included by ba.hip only).
+//
+// Replaces what ceres::Solve does for bundle_adjustment() (NViewReconstuct.cpp:1162-1244):
+//   residual + analytic Jacobian of ReprojectCost (NView:151-183; ceres::AngleAxisRotatePoint incl. its
+//   small-angle branch), HuberLoss corrector, Jacobi column scaling, the normal-equation blocks, Schur
+//   elimination of every point block into the reduced camera system S (cameras 6 each + the shared 4
+//   intrinsics), damping, and the back-substitution / model-cost / candidate-cost pass.
+//
+// Design: NO Jacobian is ever stored.  An observation record is 24 B (camera id, u, v; its point is implied by
+// the per-point ordering) while its corrected 2x13 Jacobian would be 208 B; re-deriving it costs ~300 fp64
+// flops, i.e. less than the HBM time of reading it back (ridge ~10 flop/B).  Every kernel below therefore
+// recomputes the Jacobian rows it needs from (K, camera, point, observation).
+//
+// All reductions are deterministic (fixed-shape tree/shuffle reductions, single writer per output): no atomics.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+struct BADev {
+    // sizes / layout
+    int nc, np, nobs, n, npad, koff, fix0, fixK, cam_split, world, rank;
+    double huber_a;
+    // parameters: current and candidate
+    const double* K; const double* ext; const double* pts;
+    double* Kc; double* extc; double* ptsc;
+    // observations ordered by point
+    const int* pt_start; const int* ocam; const double* ouv;
+    // per-camera lists (indices into the by-point ordering) and their points
+    const int* cam_start; const int* cam_obs; const int* opt;
+    // column scaling (cam side: npad entries; points: 3 np)
+    const double* scale_c; const double* scale_p;
+    // per point
+    double* Vinv; double* bp; double* WK; double* colsq_p;
+    // reduced system message: S (npad x npad) | rhs (npad) | diagU (npad) | graw (npad) | scal
+    double* S; double* rhs; double* diagU; double* graw; double* scal;
+    // partials
+    double* part_pt;    // [pt blocks][16]
+    double* part_cam;   // [nc][cam_split][80]
+    double* part_back;  // [pt blocks][4]
+    // solution of the reduced system (scaled coordinates, y; step = -y)
+    const double* y;
+    double radius, min_diag, max_diag;
+};
+
+#define SCAL_COST 0
+#define SCAL_GMAX_SLOTS 8     // scal[8 + rank] = local max |gradient| over this rank's points
+
+__device__ __forceinline__ int cam_off(const BADev& P, int c) { return (P.fix0 && c == 0) ? -1 : 6 * (c - P.fix0); }
+
+// Corrected residual and Jacobian blocks of one observation, column-scaled; blocks of constant parameters are 0.
+struct ObsLin {
+    double r[2];
+    double EK[2][4];   // d r / d (fx fy cx cy)
+    double Ec[2][6];   // d r / d (angle-axis, t)
+    double F[2][3];    // d r / d X
+    double rho0;       // rho(|r|^2) (cost = 1/2 rho0)
+};
+
+__device__ __forceinline__ void project_point(const double* __restrict__ e, const double X[3], double p[3])
+{
+    const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    if (th2 > DBL_EPSILON) {
+        const double th = sqrt(th2);
+        double s, c; sincos(th, &s, &c);
+        const double inv = 1.0 / th;
+        const double w0 = e[0] * inv, w1 = e[1] * inv, w2 = e[2] * inv;
+        const double wx0 = w1 * X[2] - w2 * X[1], wx1 = w2 * X[0] - w0 * X[2], wx2 = w0 * X[1] - w1 * X[0];
+        const double tmp = (w0 * X[0] + w1 * X[1] + w2 * X[2]) * (1.0 - c);
+        p[0] = X[0] * c + wx0 * s + w0 * tmp;
+        p[1] = X[1] * c + wx1 * s + w1 * tmp;
+        p[2] = X[2] * c + wx2 * s + w2 * tmp;
+    } else {
+        p[0] = X[0] + (e[1] * X[2] - e[2] * X[1]);
+        p[1] = X[1] + (e[2] * X[0] - e[0] * X[2]);
+        p[2] = X[2] + (e[0] * X[1] - e[1] * X[0]);
+    }
+    p[0] += e[3]; p[1] += e[4]; p[2] += e[5];
+}
+
+__device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1)
+{
+    if (a > 0.0 && s > a * a) { const double r = sqrt(s); rho0 = 2.0 * a * r - a * a; rho1 = fmax(DBL_MIN, a / r); }
+    else { rho0 = s; rho1 = 1.0; }
+}
+
+// cost only: 1/2 rho(|r|^2)
+__device__ __forceinline__ double obs_cost(const double* __restrict__ K4, const double* __restrict__ e, const double X[3],
+                                           double u, double v, double huber_a)
+{
+    double p[3];
+    project_point(e, X, p);
+    const double r0 = K4[0] * (p[0] / p[2]) + K4[2] - u;
+    const double r1 = K4[1] * (p[1] / p[2]) + K4[3] - v;
+    double rho0, rho1;
+    huber_rho(huber_a, r0 * r0 + r1 * r1, rho0, rho1);
+    return 0.5 * rho0;
+}
+
+__device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, const double* __restrict__ e, const double X[3],
+                                              double u, double v, double huber_a,
+                                              const double* __restrict__ sK /*4 or null*/, const double* __restrict__ sc /*6 or null*/,
+                                              const double sp[3], ObsLin& o)
+{
+    double p[3], R[3][3], dpw[3][3];   // dpw[m][k] = d p_k / d omega_m
+    const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    if (th2 > DBL_EPSILON) {
+        const double th = sqrt(th2);
+        double s, c; sincos(th, &s, &c);
+        const double inv = 1.0 / th;
+        const double w[3] = { e[0] * inv, e[1] * inv, e[2] * inv };
+        const double wx[3] = { w[1] * X[2] - w[2] * X[1], w[2] * X[0] - w[0] * X[2], w[0] * X[1] - w[1] * X[0] };
+        const double dot = w[0] * X[0] + w[1] * X[1] + w[2] * X[2];
+        const double omc = 1.0 - c, tmp = dot * omc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = X[k] * c + wx[k] * s + w[k] * tmp;
+        // R = c I + s [w]x + (1-c) w w'
+        R[0][0] = c + omc * w[0] * w[0];       R[0][1] = -s * w[2] + omc * w[0] * w[1]; R[0][2] = s * w[1] + omc * w[0] * w[2];
+        R[1][0] = s * w[2] + omc * w[1] * w[0]; R[1][1] = c + omc * w[1] * w[1];        R[1][2] = -s * w[0] + omc * w[1] * w[2];
+        R[2][0] = -s * w[1] + omc * w[2] * w[0]; R[2][1] = s * w[0] + omc * w[2] * w[1]; R[2][2] = c + omc * w[2] * w[2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            double dw[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dw[k] = ((k == m ? 1.0 : 0.0) - w[k] * w[m]) * inv;
+            const double dc = -s * w[m], ds = c * w[m];
+            const double dwx[3] = { dw[1] * X[2] - dw[2] * X[1], dw[2] * X[0] - dw[0] * X[2], dw[0] * X[1] - dw[1] * X[0] };
+            const double ddot = dw[0] * X[0] + dw[1] * X[1] + dw[2] * X[2];
+            const double dtmp = ddot * omc + dot * s * w[m];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dpw[m][k] = X[k] * dc + dwx[k] * s + wx[k] * ds + dw[k] * tmp + w[k] * dtmp;
+        }
+    } else {
+        p[0] = X[0] + (e[1] * X[2] - e[2] * X[1]);
+        p[1] = X[1] + (e[2] * X[0] - e[0] * X[2]);
+        p[2] = X[2] + (e[0] * X[1] - e[1] * X[0]);
+        R[0][0] = 1.0;   R[0][1] = -e[2]; R[0][2] = e[1];
+        R[1][0] = e[2];  R[1][1] = 1.0;   R[1][2] = -e[0];
+        R[2][0] = -e[1]; R[2][1] = e[0];  R[2][2] = 1.0;
+        // d(omega x X)/d omega_m = e_m x X
+        dpw[0][0] = 0.0;   dpw[0][1] = -X[2]; dpw[0][2] = X[1];
+        dpw[1][0] = X[2];  dpw[1][1] = 0.0;   dpw[1][2] = -X[0];
+        dpw[2][0] = -X[1]; dpw[2][1] = X[0];  dpw[2][2] = 0.0;
+    }
+    p[0] += e[3]; p[1] += e[4]; p[2] += e[5];
+    const double iz = 1.0 / p[2];
+    const double x = p[0] * iz, y = p[1] * iz;
+    double r0 = K4[0] * x + K4[2] - u;
+    double r1 = K4[1] * y + K4[3] - v;
+    double rho0, rho1;
+    huber_rho(huber_a, r0 * r0 + r1 * r1, rho0, rho1);
+    const double sq = sqrt(rho1);
+    o.rho0 = rho0;
+    o.r[0] = sq * r0; o.r[1] = sq * r1;
+    // d(u,v)/dp, pre-multiplied by the corrector
+    const double a00 = sq * K4[0] * iz, a02 = -sq * K4[0] * x * iz;
+    const double a11 = sq * K4[1] * iz, a12 = -sq * K4[1] * y * iz;
+    if (sK) {
+        o.EK[0][0] = sq * x * sK[0]; o.EK[0][1] = 0.0; o.EK[0][2] = sq * sK[2]; o.EK[0][3] = 0.0;
+        o.EK[1][0] = 0.0; o.EK[1][1] = sq * y * sK[1]; o.EK[1][2] = 0.0; o.EK[1][3] = sq * sK[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o.EK[0][j] = 0.0; o.EK[1][j] = 0.0; }
+    }
+    if (sc) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            o.Ec[0][m] = (a00 * dpw[m][0] + a02 * dpw[m][2]) * sc[m];
+            o.Ec[1][m] = (a11 * dpw[m][1] + a12 * dpw[m][2]) * sc[m];
+        }
+        o.Ec[0][3] = a00 * sc[3]; o.Ec[0][4] = 0.0;         o.Ec[0][5] = a02 * sc[5];
+        o.Ec[1][3] = 0.0;         o.Ec[1][4] = a11 * sc[4]; o.Ec[1][5] = a12 * sc[5];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { o.Ec[0][j] = 0.0; o.Ec[1][j] = 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o.F[0][j] = (a00 * R[0][j] + a02 * R[2][j]) * sp[j];
+        o.F[1][j] = (a11 * R[1][j] + a12 * R[2][j]) * sp[j];
+    }
+}
+
+// symmetric 3x3 inverse through Cholesky; V = [v00 v10 v11 v20 v21 v22] (lower), same layout out.
+__device__ __forceinline__ bool inv3_spd(const double V[6], double Vi[6])
+{
+    bool ok = V[0] > 0.0;
+    const double l00 = sqrt(V[0]);
+    const double l10 = V[1] / l00, l20 = V[3] / l00;
+    const double d11 = V[2] - l10 * l10; ok = ok && d11 > 0.0;
+    const double l11 = sqrt(d11);
+    const double l21 = (V[4] - l20 * l10) / l11;
+    const double d22 = V[5] - l20 * l20 - l21 * l21; ok = ok && d22 > 0.0;
+    const double l22 = sqrt(d22);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    Vi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    Vi[1] = i10 * i11 + i20 * i21;
+    Vi[2] = i11 * i11 + i21 * i21;
+    Vi[3] = i20 * i22;
+    Vi[4] = i21 * i22;
+    Vi[5] = i22 * i22;
+    return ok;
+}
+// y = Vi (sym, lower-packed) * x
+__device__ __forceinline__ void symv3(const double Vi[6], const double x[3], double y[3])
+{
+    y[0] = Vi[0] * x[0] + Vi[1] * x[1] + Vi[3] * x[2];
+    y[1] = Vi[1] * x[0] + Vi[2] * x[1] + Vi[4] * x[2];
+    y[2] = Vi[3] * x[0] + Vi[4] * x[1] + Vi[5] * x[2];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_pt: one thread per point.  V_p = sum F'F + D_p^2, b_p = sum F'r, WK_p = sum EK'F; stores V_p^-1, b_p, WK_p,
+// the raw squared column norms, and per-block partials of: cost, the point-eliminated intrinsic terms
+// SKK = sum WK V^-1 WK' (10), gK = sum WK V^-1 b (4), max |gradient| over the block's point columns.
+// part_pt[block][16] = { cost, SKK[10], gK[4], gmax }
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict__ err)
+{
+    __shared__ double red[4][16];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    if (p < P.np) {
+        const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
+        const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
+        double V[6] = { 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 }, WK[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) WK[i] = 0.0;
+        double cost = 0.0;
+        const int s0 = P.pt_start[p], s1 = P.pt_start[p + 1];
+        for (int k = s0; k < s1; ++k) {
+            const int c = P.ocam[k];
+            ObsLin o;
+            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
+                          P.fixK ? nullptr : P.scale_c + P.koff, nullptr, sp, o);
+            cost += 0.5 * o.rho0;
+            V[0] += o.F[0][0] * o.F[0][0] + o.F[1][0] * o.F[1][0];
+            V[1] += o.F[0][1] * o.F[0][0] + o.F[1][1] * o.F[1][0];
+            V[2] += o.F[0][1] * o.F[0][1] + o.F[1][1] * o.F[1][1];
+            V[3] += o.F[0][2] * o.F[0][0] + o.F[1][2] * o.F[1][0];
+            V[4] += o.F[0][2] * o.F[0][1] + o.F[1][2] * o.F[1][1];
+            V[5] += o.F[0][2] * o.F[0][2] + o.F[1][2] * o.F[1][2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b[j] += o.F[0][j] * o.r[0] + o.F[1][j] * o.r[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) WK[3 * i + j] += o.EK[0][i] * o.F[0][j] + o.EK[1][i] * o.F[1][j];
+        }
+        const double cs[3] = { V[0], V[2], V[5] };
+        P.colsq_p[3 * p] = cs[0]; P.colsq_p[3 * p + 1] = cs[1]; P.colsq_p[3 * p + 2] = cs[2];
+        V[0] += fmin(fmax(cs[0], P.min_diag), P.max_diag) / P.radius;
+        V[2] += fmin(fmax(cs[1], P.min_diag), P.max_diag) / P.radius;
+        V[5] += fmin(fmax(cs[2], P.min_diag), P.max_diag) / P.radius;
+        double Vi[6];
+        if (!inv3_spd(V, Vi)) *err = 1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) P.Vinv[6 * (size_t)p + i] = Vi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) P.bp[3 * (size_t)p + i] = b[i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) P.WK[12 * (size_t)p + i] = WK[i];
+        // T = WK Vi (4x3); SKK = T WK' ; gK = T b
+        double T[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) symv3(Vi, &WK[3 * i], &T[3 * i]);
+        acc[0] = cost;
+        int q = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                acc[q++] = T[3 * i] * WK[3 * j] + T[3 * i + 1] * WK[3 * j + 1] + T[3 * i + 2] * WK[3 * j + 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[11 + i] = T[3 * i] * b[0] + T[3 * i + 1] * b[1] + T[3 * i + 2] * b[2];
+        acc[15] = fmax(fabs(b[0] / sp[0]), fmax(fabs(b[1] / sp[1]), fabs(b[2] / sp[2])));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) acc[i] = wave_sum(acc[i]);
+    acc[15] = wave_max(acc[15]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x;
+        double v = red[0][i];
+        for (int w = 1; w < 4; ++w) v = (i == 15) ? fmax(v, red[w][i]) : v + red[w][i];
+        P.part_pt[16 * (size_t)blockIdx.x + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_cam: block (c, split) walks a slice of camera c's observations.  Per thread 80 accumulators:
+//   [0,21)  Scc  = Ec'Ec - T Wc'        (lower 6x6)          T = (Ec'F) V^-1
+//   [21,45) ScK  = Ec'EK - T WK_p'      (6x4)
+//   [45,51) rhs_c = Ec'r - T b_p
+//   [51,61) UKK  = EK'EK                (lower 4x4)
+//   [61,65) gK   = EK'r
+//   [65,71) diagU_c = diag(Ec'Ec)
+//   [71,77) graw_c = Ec'r
+// ------------------------------------------------------------------------------------------------
+#define CAMACC 80
+__global__ __launch_bounds__(256) void ba_camera_kernel(BADev P)
+{
+    __shared__ double red[4][CAMACC];
+    const int c = blockIdx.x, sp_i = blockIdx.y;
+    const int co = cam_off(P, c);
+    double acc[CAMACC];
+#pragma unroll
+    for (int i = 0; i < CAMACC; ++i) acc[i] = 0.0;
+    const int s0 = P.cam_start[c], s1 = P.cam_start[c + 1];
+    const int len = s1 - s0, per = (len + P.cam_split - 1) / P.cam_split;
+    const int b0 = s0 + sp_i * per;
+    int b1 = b0 + per; if (b1 > s1) b1 = s1;
+    const double* sc = co < 0 ? nullptr : P.scale_c + co;
+    const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
+    for (int q = b0 + threadIdx.x; q < b1; q += 256) {
+        const int k = P.cam_obs[q], p = P.opt[k];
+        const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
+        const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
+        ObsLin o;
+        obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, sc, spp, o);
+        double Vi[6], b[3], WK[12];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = P.bp[3 * (size_t)p + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) WK[i] = P.WK[12 * (size_t)p + i];
+        double W[6][3], T[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) W[i][j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
+            symv3(Vi, W[i], T[i]);
+        }
+        int a = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                acc[a++] += o.Ec[0][i] * o.Ec[0][j] + o.Ec[1][i] * o.Ec[1][j]
+                            - (T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[a++] += o.Ec[0][i] * o.EK[0][j] + o.Ec[1][i] * o.EK[1][j]
+                            - (T[i][0] * WK[3 * j] + T[i][1] * WK[3 * j + 1] + T[i][2] * WK[3 * j + 2]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[a++] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1] - (T[i][0] * b[0] + T[i][1] * b[1] + T[i][2] * b[2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) acc[a++] += o.EK[0][i] * o.EK[0][j] + o.EK[1][i] * o.EK[1][j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[a++] += o.EK[0][i] * o.r[0] + o.EK[1][i] * o.r[1];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[a++] += o.Ec[0][i] * o.Ec[0][i] + o.Ec[1][i] * o.Ec[1][i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[a++] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 77; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < CAMACC; ++i) red[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < CAMACC) {
+        const int i = threadIdx.x;
+        P.part_cam[((size_t)c * P.cam_split + sp_i) * CAMACC + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_finalize: block c < nc sums camera c's split partials and writes its S blocks / rhs / diagU / graw;
+// block nc reduces the intrinsic terms: S_KK = sum_c UKK - sum_blocks SKK, rhs_K, cost, local gmax.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_blocks)
+{
+    __shared__ double sh[256];
+    const int tid = threadIdx.x;
+    const int ld = P.npad;
+    if ((int)blockIdx.x < P.nc) {
+        const int c = blockIdx.x, co = cam_off(P, c);
+        if (co < 0) return;
+        if (tid < CAMACC) {
+            double v = 0.0;
+            for (int s = 0; s < P.cam_split; ++s) v += P.part_cam[((size_t)c * P.cam_split + s) * CAMACC + tid];
+            sh[tid] = v;
+        }
+        __syncthreads();
+        if (tid < 36) {
+            const int i = tid / 6, j = tid % 6;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            P.S[(size_t)(co + i) * ld + co + j] = sh[hi * (hi + 1) / 2 + lo];
+        } else if (tid < 60 && !P.fixK) {
+            const int q = tid - 36, i = q / 4, j = q % 4;
+            const double v = sh[21 + q];
+            P.S[(size_t)(co + i) * ld + P.koff + j] = v;
+            P.S[(size_t)(P.koff + j) * ld + co + i] = v;
+        } else if (tid >= 64 && tid < 70) {
+            const int i = tid - 64;
+            P.rhs[co + i] = sh[45 + i];
+            P.diagU[co + i] = sh[65 + i];
+            P.graw[co + i] = sh[71 + i];
+        }
+        return;
+    }
+    // intrinsic block + scalars
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    for (int b = tid; b < n_pt_blocks; b += 256) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) acc[i] += P.part_pt[16 * (size_t)b + i];
+        acc[15] = fmax(acc[15], P.part_pt[16 * (size_t)b + 15]);
+    }
+    double u[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) u[i] = 0.0;
+    for (int q = tid; q < P.nc * P.cam_split; q += 256) {
+#pragma unroll
+        for (int i = 0; i < 14; ++i) u[i] += P.part_cam[(size_t)q * CAMACC + 51 + i];
+    }
+    __shared__ double red[4][32];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) acc[i] = wave_sum(acc[i]);
+    acc[15] = wave_max(acc[15]);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) u[i] = wave_sum(u[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) red[wave][16 + i] = u[i];
+    }
+    __syncthreads();
+    if (tid < 30) {
+        double v = red[0][tid];
+        for (int w = 1; w < 4; ++w) v = (tid == 15) ? fmax(v, red[w][tid]) : v + red[w][tid];
+        sh[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        P.scal[SCAL_COST] = sh[0];
+        P.scal[SCAL_GMAX_SLOTS + P.rank] = sh[15];
+    }
+    if (!P.fixK) {
+        if (tid < 16) {
+            const int i = tid / 4, j = tid % 4;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            const int q = hi * (hi + 1) / 2 + lo;
+            P.S[(size_t)(P.koff + i) * ld + P.koff + j] = sh[16 + q] - sh[1 + q];
+        } else if (tid >= 32 && tid < 36) {
+            const int i = tid - 32;
+            P.rhs[P.koff + i] = sh[26 + i] - sh[11 + i];
+            P.graw[P.koff + i] = sh[26 + i];
+            P.diagU[P.koff + i] = sh[16 + i * (i + 1) / 2 + i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_schur: one wave per camera-camera block (a, b), a >= b, over the list of observation pairs (i in a, j in b)
+// that share a point: block -= sum T_i W_j'.  a == b (i != j: one point seen twice by one camera) adds the
+// symmetrised term onto the diagonal block written by K_finalize.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ba_schur_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_start,
+                                                      const int* __restrict__ items)
+{
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int ca = blk_cam[2 * blk], cb = blk_cam[2 * blk + 1];
+    const int oa = cam_off(P, ca), ob = cam_off(P, cb);
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    const int s0 = blk_start[blk], s1 = blk_start[blk + 1];
+    for (int q = s0 + lane; q < s1; q += 64) {
+        const int ki = items[2 * q], kj = items[2 * q + 1];
+        const int p = P.opt[ki];
+        const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
+        const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
+        double Vi[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
+        double T[6][3], W[6][3];
+        {
+            ObsLin o;
+            obs_linearize(P.K, P.ext + 6 * ca, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double w[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w[j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
+                symv3(Vi, w, T[i]);
+            }
+        }
+        {
+            ObsLin o;
+            obs_linearize(P.K, P.ext + 6 * cb, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) W[i][j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] += T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2];
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
+    // lane q < 36 keeps element q (static selection, no dynamic register indexing)
+    double mine = 0.0, mineT = 0.0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        if (lane == i) mine = acc[i];
+        if (lane == (i % 6) * 6 + i / 6) mineT = acc[i];
+    }
+    if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        const int ld = P.npad;
+        if (ca != cb) {
+            P.S[(size_t)(oa + i) * ld + ob + j] = -mine;
+            P.S[(size_t)(ob + j) * ld + oa + i] = -mine;
+        } else {
+            P.S[(size_t)(oa + i) * ld + oa + j] -= mine + mineT;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_damp (after the all-reduce): S_ii += clamp(diagU_i)/radius, padding rows get a unit diagonal;
+// scal[1] = max |graw_i / scale_i| over the camera-side columns, folded with the per-rank point maxima.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_damp_kernel(BADev P)
+{
+    __shared__ double red[4];
+    double g = 0.0;
+    for (int i = threadIdx.x; i < P.npad; i += 256) {
+        if (i < P.n) {
+            const double d = fmin(fmax(P.diagU[i], P.min_diag), P.max_diag) / P.radius;
+            P.S[(size_t)i * P.npad + i] += d;
+            g = fmax(g, fabs(P.graw[i] / P.scale_c[i]));
+        } else {
+            P.S[(size_t)i * P.npad + i] = 1.0;
+            P.rhs[i] = 0.0;
+        }
+    }
+    g = wave_max(g);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        for (int r = 0; r < P.world; ++r) m = fmax(m, P.scal[SCAL_GMAX_SLOTS + r]);
+        P.scal[1] = m;
+    }
+}
+
+// jacobi scaling from the raw column norms (first linearisation, scale == 1): s = 1 / (1 + sqrt(colsq))
+__global__ void ba_scale_kernel(const double* __restrict__ colsq, double* __restrict__ scale, int n, int enabled)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) scale[i] = enabled ? 1.0 / (1.0 + sqrt(colsq[i])) : 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_camstep: candidate intrinsics / cameras = x + scale * (-y); out[0] = |delta_cam|^2, out[1] = |x_cand,cam|^2
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __restrict__ out2)
+{
+    __shared__ double red[4][2];
+    double dn = 0.0, xn = 0.0;
+    for (int i = threadIdx.x; i < 6 * P.nc + 4; i += 256) {
+        double x, d = 0.0;
+        if (i < 4) {
+            x = P.K[i];
+            if (!P.fixK) d = -P.y[P.koff + i] * P.scale_c[P.koff + i];
+            P.Kc[i] = x + d;
+            if (!P.fixK) { dn += d * d; xn += (x + d) * (x + d); }
+        } else {
+            const int c = (i - 4) / 6, j = (i - 4) % 6;
+            const int co = cam_off(P, c);
+            x = P.ext[i - 4];
+            if (co >= 0) d = -P.y[co + j] * P.scale_c[co + j];
+            P.extc[i - 4] = x + d;
+            if (co >= 0) { dn += d * d; xn += (x + d) * (x + d); }
+        }
+    }
+    dn = wave_sum(dn); xn = wave_sum(xn);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = dn; red[threadIdx.x >> 6][1] = xn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        out2[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_back: one thread per point.  y_p = V^-1 (b_p - sum F'(E y_c)), step_p = -y_p, candidate point,
+// model cost change -sum m.(r + m/2) with m = J step, candidate cost at (Kc, extc, ptsc).
+// part_back[block][4] = { model_cost_change, candidate_cost, |delta_p|^2, |x_cand,p|^2 }
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
+{
+    __shared__ double red[4][4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double acc[4] = { 0, 0, 0, 0 };
+    if (p < P.np) {
+        const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
+        const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
+        double t[3] = { P.bp[3 * (size_t)p], P.bp[3 * (size_t)p + 1], P.bp[3 * (size_t)p + 2] };
+        double Vi[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
+        const int s0 = P.pt_start[p], s1 = P.pt_start[p + 1];
+        const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
+        double yK[4] = { 0, 0, 0, 0 };
+        if (!P.fixK) { yK[0] = P.y[P.koff]; yK[1] = P.y[P.koff + 1]; yK[2] = P.y[P.koff + 2]; yK[3] = P.y[P.koff + 3]; }
+        for (int k = s0; k < s1; ++k) {
+            const int c = P.ocam[k], co = cam_off(P, c);
+            ObsLin o;
+            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
+            double e0 = 0.0, e1 = 0.0;
+            if (co >= 0)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double yy = P.y[co + j]; e0 += o.Ec[0][j] * yy; e1 += o.Ec[1][j] * yy; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e0 += o.EK[0][j] * yK[j]; e1 += o.EK[1][j] * yK[j]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[j] -= o.F[0][j] * e0 + o.F[1][j] * e1;
+        }
+        double yp[3];
+        symv3(Vi, t, yp);
+        const double d[3] = { -yp[0] * sp[0], -yp[1] * sp[1], -yp[2] * sp[2] };
+        const double Xc[3] = { X[0] + d[0], X[1] + d[1], X[2] + d[2] };
+        P.ptsc[3 * (size_t)p] = Xc[0]; P.ptsc[3 * (size_t)p + 1] = Xc[1]; P.ptsc[3 * (size_t)p + 2] = Xc[2];
+        acc[2] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        acc[3] = Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+        for (int k = s0; k < s1; ++k) {
+            const int c = P.ocam[k], co = cam_off(P, c);
+            ObsLin o;
+            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
+            double m0 = 0.0, m1 = 0.0;
+            if (co >= 0)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double yy = P.y[co + j]; m0 -= o.Ec[0][j] * yy; m1 -= o.Ec[1][j] * yy; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m0 -= o.EK[0][j] * yK[j]; m1 -= o.EK[1][j] * yK[j]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { m0 -= o.F[0][j] * yp[j]; m1 -= o.F[1][j] * yp[j]; }
+            acc[0] -= m0 * (o.r[0] + 0.5 * m0) + m1 * (o.r[1] + 0.5 * m1);
+            acc[1] += obs_cost(P.Kc, P.extc + 6 * c, Xc, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        P.part_back[4 * (size_t)blockIdx.x + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// out4 = sum over blocks of part_back
+__global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out4)
+{
+    __shared__ double red[4][4];
+    double acc[4] = { 0, 0, 0, 0 };
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += part[4 * (size_t)b + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 4) out4[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// cost only at the current parameters (used for |x| bookkeeping at start-up): not needed separately --
+// K_pt already returns the cost of the linearisation point.
+
+// |x|^2 over the free parameters of the current point (start-up only)
+__global__ __launch_bounds__(256) void ba_xnorm_kernel(BADev P, double* __restrict__ out)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    const size_t total = 4 + 6 * (size_t)P.nc + 3 * (size_t)P.np;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        double v;
+        if (i < 4) v = P.fixK ? 0.0 : P.K[i];
+        else if (i < 4 + 6 * (size_t)P.nc) { const int c = (int)((i - 4) / 6); v = cam_off(P, c) < 0 ? 0.0 : P.ext[i - 4]; }
+        else v = P.pts[i - 4 - 6 * (size_t)P.nc];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}

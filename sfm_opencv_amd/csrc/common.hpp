@@ -1,0 +1,88 @@
+// common.hpp -- internal definitions shared by the translation units of libsfmhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sfmhip.h"
+
+struct sfmhip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream every launch goes to (own_stream or an external one)
+    std::string last_error;
+    // grow-only device scratch (kNN partial results, pair descriptors, rescore lists)
+    void*  scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void*  scratch2 = nullptr;
+    size_t scratch2_bytes = 0;
+    int    num_cus = 256;
+};
+
+#define SFM_HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+            return SFMHIP_E_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+#define SFM_ARG_CHECK(ctx, cond)                                                                 \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            if (ctx) (ctx)->last_error = std::string("bad argument: ") + #cond;                  \
+            return SFMHIP_E_ARG;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+static inline int sfm_scratch(sfmhip_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        // the stream may still be using the old block: drain it before freeing
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) SFM_HIP_TRY(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        SFM_HIP_TRY(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return SFMHIP_OK;
+}
+static inline int sfm_scratch2(sfmhip_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch2_bytes) {
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch2) SFM_HIP_TRY(ctx, hipFree(ctx->scratch2));
+        ctx->scratch2 = nullptr; ctx->scratch2_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        SFM_HIP_TRY(ctx, hipMalloc(&ctx->scratch2, want));
+        ctx->scratch2_bytes = want;
+    }
+    *out = ctx->scratch2;
+    return SFMHIP_OK;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int ceil_div(int x, int m) { return (x + m - 1) / m; }
+
+// descriptor set (one image), see match.hip
+struct sfmhip_descset {
+    sfmhip_ctx* ctx = nullptr;
+    int kind = 0;
+    int rows = 0, rows_pad = 0;      // rows_pad: multiple of 128
+    int dim = 0;                      // L2: elements; Hamming: bytes
+    // L2
+    const float* d_f32 = nullptr; size_t ld = 0; bool owns_f32 = false;
+    int dim_pad = 0;                  // multiple of 32 (int8 copy row length in bytes)
+    int8_t* d_i8 = nullptr;           // rows_pad x dim_pad, value - 128; pad rows zero
+    int32_t* d_norm = nullptr;        // rows_pad: sum (value-128)^2; pad rows = PAD_NORM
+    int exact_u8 = 0;                 // every value an integer in [0,255] and dim <= 128
+    // Hamming2
+    uint32_t* d_u32 = nullptr;        // rows_pad x 16 words (64 B rows, zero padded)
+    int* d_flag = nullptr;
+};

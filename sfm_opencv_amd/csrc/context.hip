@@ -1,0 +1,80 @@
+// context.hip -- context lifetime + the host-only ratio tail of libsfmhip.so.
+#include "common.hpp"
+#include <cfloat>
+
+extern "C" {
+
+const char* sfmhip_version(void) { return "sfmhip 0.1 (gfx950)"; }
+
+int sfmhip_create(int device, sfmhip_ctx** out)
+{
+    if (!out) return SFMHIP_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SFMHIP_E_NODEVICE;
+    if (device < 0 || device >= ndev) return SFMHIP_E_ARG;
+    sfmhip_ctx* ctx = new sfmhip_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return SFMHIP_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFMHIP_E_HIP; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return SFMHIP_OK;
+}
+
+void sfmhip_destroy(sfmhip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return SFMHIP_E_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SFMHIP_OK;
+}
+
+int sfmhip_synchronize(sfmhip_ctx* ctx)
+{
+    if (!ctx) return SFMHIP_E_ARG;
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SFMHIP_OK;
+}
+
+const char* sfmhip_last_error(sfmhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+// match_features' ratio tail on the host, reference arithmetic (NViewReconstuct.cpp:880-908):
+// the ratio compare promotes to double (float > 0.6 * float), the absolute gate stays float.
+int sfmhip_ratio_filter(const int32_t* idx2, const float* dist2, int nq,
+                        double ratio, float floor_, float mult, sfm_dmatch* out, int* n_out)
+{
+    if (!idx2 || !dist2 || !out || !n_out || nq < 0) return SFMHIP_E_ARG;
+    float min_dist = FLT_MAX;
+    for (int i = 0; i < nq; ++i) {
+        if (idx2[2 * i] < 0 || idx2[2 * i + 1] < 0) continue;
+        const float d0 = dist2[2 * i], d1 = dist2[2 * i + 1];
+        if ((double)d0 > ratio * (double)d1) continue;
+        if (d0 < min_dist) min_dist = d0;
+    }
+    const float gate = mult * (min_dist > floor_ ? min_dist : floor_);
+    int n = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (idx2[2 * i] < 0 || idx2[2 * i + 1] < 0) continue;
+        const float d0 = dist2[2 * i], d1 = dist2[2 * i + 1];
+        if ((double)d0 > ratio * (double)d1 || d0 > gate) continue;
+        out[n].queryIdx = i; out[n].trainIdx = idx2[2 * i]; out[n].imgIdx = 0; out[n].distance = d0;
+        ++n;
+    }
+    *n_out = n;
+    return SFMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1000 @@
+// match.hip -- brute-force kNN-2 descriptor matching for gfx950 (replaces cv::BFMatcher::knnMatch(k=2)
+// + the ratio tail of match_features, NViewReconstuct.cpp:873-913; L2 twin TwoViewReconstruct.cpp:156-194).
+//
+// Paths
+//   * int8 MFMA path (v_mfma_i32_32x32x32_i8): OpenCV SIFT descriptors are integer-valued floats in
+//     [0,255]; biased to int8 (v-128), |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' is exact in int32, so the
+//     kNN ordering is exact in any summation order.  The reference orders by sqrtf(d^2) (float32): distinct
+//     integers d^2 >= 2^22 can round to the same float, so rows whose 2nd-best d^2 >= 2^22 are re-scored by
+//   * the exact fp32 path: direct-difference sum in the accumulation order of OpenCV's SSE2 normL2Sqr_
+//     (see oracle/orc_match.c), correctly rounded sqrtf, ordering key (sqrt bits, train index).
+//   * Hamming2 (AKAZE, the live reference configuration): VALU popcount of non-zero 2-bit cells.
+// Tie-breaking everywhere: smaller distance, then smaller train index (cv::batchDistance's stable insertion).
+#include "common.hpp"
+// float32 results must be bit-exact with the CPU restatement: no FMA contraction, correctly rounded sqrt
+// (HIP's __fsqrt_rn/__fmul_rn are NOT the rounded forms on this toolchain: native sqrt / contractible mul).
+#pragma clang fp contract(off)
+#include <cfloat>
+#include <climits>
+
+#define PAD_NORM 8388607      // 2^23-1: larger than any real partial key, never selected
+#define KEY_INVALID 0x7fffffffffffffffLL
+#define RESCORE_D2 4194304    // 2^22: below this, distinct integers have distinct float32 square roots
+
+typedef int   v4i  __attribute__((ext_vector_type(4)));
+typedef int   v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// descriptor preparation
+// ------------------------------------------------------------------------------------------------
+// one wave per row: exactness check (integer in [0,255]), int8 copy (v-128, zero padded), squared norm
+__global__ void prep_l2_kernel(const float* __restrict__ src, size_t ld, int rows, int dim, int dim_pad,
+                               int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int rows_pad)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows_pad) return;
+    if (row >= rows) {
+        for (int k = lane; k < dim_pad; k += 64) dst[(size_t)row * dim_pad + k] = 0;
+        if (lane == 0) norm[row] = PAD_NORM;
+        return;
+    }
+    int acc = 0, bad = 0;
+    for (int k = lane; k < dim_pad; k += 64) {
+        int8_t o = 0;
+        if (k < dim) {
+            const float v = src[(size_t)row * ld + k];
+            const float r = rintf(v);
+            if (!(v >= 0.0f && v <= 255.0f) || r != v) bad = 1;
+            const int q = (int)fminf(fmaxf(r, 0.0f), 255.0f) - 128;
+            o = (int8_t)q;
+            acc += q * q;
+        }
+        dst[(size_t)row * dim_pad + k] = o;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) norm[row] = acc;
+    if (bad) atomicOr(flag, 1);
+}
+
+// Hamming: copy rows into 64-byte zero-padded rows (16 dwords)
+__global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                    uint8_t* __restrict__ dst, int rows_pad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows_pad * 64) return;
+    const int row = (int)(i >> 6), k = (int)(i & 63);
+    dst[i] = (row < rows && k < nbytes) ? src[(size_t)row * ld + k] : (uint8_t)0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-pair descriptor for the batched kernels
+// ------------------------------------------------------------------------------------------------
+struct PairDesc {
+    const void* q; const void* t;          // int8 (mfma path) / u32 rows (hamming)
+    const float* qf; const float* tf;      // float rows (exact path)
+    const int32_t* qn; const int32_t* tn;  // squared norms of the biased int8 rows
+    int nq, nt, nq_pad, nt_pad, dim;
+    int nchunks, chunk_rows;               // train chunking (chunk_rows multiple of 128)
+    long long part_off;                    // offset (entries of two keys) into the partial buffer, [row][chunk]
+    long long out_off;                     // row offset into idx2 / dist2
+    long long list_off;                    // offset into the rescore row list
+    size_t ldq, ldt;                       // float row strides (elements)
+};
+
+// top-2 merge of sorted pairs (a1<=a2), (b1<=b2)
+__device__ __forceinline__ void merge2(long long& a1, long long& a2, long long b1, long long b2)
+{
+    const long long lo = a1 < b1 ? a1 : b1;
+    const long long hi = a1 < b1 ? b1 : a1;
+    const long long m2 = a2 < b2 ? a2 : b2;
+    a1 = lo; a2 = hi < m2 ? hi : m2;
+}
+__device__ __forceinline__ long long shfl_xor_ll(long long v, int off)
+{
+    int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
+    lo = __shfl_xor(lo, off); hi = __shfl_xor(hi, off);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8 MFMA kNN-2.  grid = (query blocks of 128, chunks, pairs), block = 256 (4 waves x 32 query rows).
+// LDS: two buffers of 128 train rows x DP bytes, 16-byte chunks XOR-swizzled so that the 16 lanes of a
+// ds_read_b128 group (16 different rows, same k-chunk) hit 16 different slots of the 256-byte bank row.
+// Partial output: for each (query row, chunk): two 64-bit keys (d2 << 32 | train index), ascending.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part)
+{
+    constexpr int DP = 32 * KS;          // bytes per row
+    constexpr int CH = DP / 16;          // 16-byte chunks per row
+    constexpr int PASSES = (128 * CH) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4];
+    const PairDesc pd = pairs[blockIdx.z];
+    const int qb = blockIdx.x, chunk = blockIdx.y;
+    if (qb * 128 >= pd.nq_pad || chunk >= pd.nchunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int8_t* Q = (const int8_t*)pd.q;
+    const int8_t* T = (const int8_t*)pd.t;
+    const int t_begin = chunk * pd.chunk_rows;
+    int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt_pad) t_end = pd.nt_pad;
+    const int nblocks = (t_end - t_begin) / 128;
+    const int q0 = qb * 128 + wave * 32;
+
+    // stationary operand: 32 query rows per wave, lane holds row l31, k bytes [32 ks + 16 half, +16)
+    v4i afrag[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        afrag[ks] = *(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
+
+    int best1[16], best2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { best1[i] = INT_MAX; best2[i] = INT_MAX; }
+
+    int* lds_norm = (int*)(lds + 2 * 128 * DP);
+    v4i stage[PASSES];
+    int stage_norm = 0;
+    auto g_load = [&](int blk) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
+            stage[p] = *(const v4i*)(T + (size_t)(t_begin + blk * 128 + r) * DP + 16 * c);
+        }
+        if (tid < 128) stage_norm = pd.tn[t_begin + blk * 128 + tid];
+    };
+    auto l_store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
+            *(v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
+        }
+        if (tid < 128) lds_norm[buf * 128 + tid] = stage_norm;
+    };
+
+    if (nblocks > 0) { g_load(0); l_store(0); }
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int buf = blk & 1;
+        if (blk + 1 < nblocks) g_load(blk + 1);
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int r = tile * 32 + l31;
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = 2 * ks + half;
+                const v4i b = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], b, acc, 0, 0, 0);
+            }
+            // C[row = query (reg), col = train (lane&31)].  key = (|b'|^2 - 2 a'.b') * 128 + local tile index
+            const int nbt = lds_norm[buf * 128 + r] * 128 + (blk * 4 + tile);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = nbt - acc[i] * 256;
+                const int mx = best1[i] > key ? best1[i] : key;
+                best2[i] = best2[i] < mx ? best2[i] : mx;
+                best1[i] = best1[i] < key ? best1[i] : key;
+            }
+        }
+        if (blk + 1 < nblocks) l_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // widen to global 64-bit keys and merge across the 32 lanes that share the same query rows
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = q0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+        const int qn = pd.qn[row];
+        long long k1 = KEY_INVALID, k2 = KEY_INVALID;
+        if (best1[i] != INT_MAX) {
+            const int e = best1[i] >> 7, tl = best1[i] & 127;
+            k1 = ((long long)(e + qn) << 32) | (unsigned int)(t_begin + tl * 32 + l31);
+        }
+        if (best2[i] != INT_MAX) {
+            const int e = best2[i] >> 7, tl = best2[i] & 127;
+            k2 = ((long long)(e + qn) << 32) | (unsigned int)(t_begin + tl * 32 + l31);
+        }
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const long long o1 = shfl_xor_ll(k1, off), o2 = shfl_xor_ll(k2, off);
+            merge2(k1, k2, o1, o2);
+        }
+        if (l31 == 0) {
+            long long* o = part + 2 * (pd.part_off + (long long)row * pd.nchunks + chunk);
+            o[0] = k1; o[1] = k2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// materialised distance matrix on the int8 MFMA path (HBM-write-bound: 4 B out per 2*dim ops).
+// Operands are swapped (A = trains from LDS, B = queries in registers) so that each lane owns one query
+// column and 4 x 4 CONSECUTIVE trains: every store is a 16-byte store and four consecutive store
+// instructions complete a 128-byte line of each of the wave's 32 query rows.
+// grid = (query blocks of 128, train super-blocks of TB*128 rows), block = 256.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
+                                                         const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
+                                                         int nq, int nt, int nt_pad, int blocks_per_wg,
+                                                         float* __restrict__ dist, size_t ldd, int vec_ok)
+{
+    constexpr int DP = 32 * KS;
+    constexpr int CH = DP / 16;
+    constexpr int PASSES = (128 * CH) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int t_begin = blockIdx.y * blocks_per_wg * 128;
+    int nblocks = (nt_pad - t_begin) / 128; if (nblocks > blocks_per_wg) nblocks = blocks_per_wg;
+    if (nblocks <= 0) return;
+
+    v4i qfrag[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qfrag[ks] = *(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
+    const int qrow = q0 + l31;
+    const int qn = qnorm[qrow];
+
+    int* lds_norm = (int*)(lds + 2 * 128 * DP);
+    v4i stage[PASSES];
+    int stage_norm = 0;
+    auto g_load = [&](int blk) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
+            stage[p] = *(const v4i*)(T + (size_t)(t_begin + blk * 128 + r) * DP + 16 * c);
+        }
+        if (tid < 128) stage_norm = tnorm[t_begin + blk * 128 + tid];
+    };
+    auto l_store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
+            *(v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
+        }
+        if (tid < 128) lds_norm[buf * 128 + tid] = stage_norm;
+    };
+
+    g_load(0); l_store(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int buf = blk & 1;
+        if (blk + 1 < nblocks) g_load(blk + 1);
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int r = tile * 32 + l31;
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = 2 * ks + half;
+                const v4i a = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qfrag[ks], acc, 0, 0, 0);
+            }
+            // C[row = train (reg), col = query (lane&31)]: regs 4g..4g+3 <-> trains 8g + 4 half + {0,1,2,3}
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int tl = tile * 32 + 8 * g + 4 * half;
+                const v4i tn = *(const v4i*)(lds_norm + buf * 128 + tl);
+                const int tg = t_begin + blk * 128 + tl;
+                float4 o;
+                o.x = sqrtf((float)(qn + tn.x - 2 * acc[4 * g + 0]));
+                o.y = sqrtf((float)(qn + tn.y - 2 * acc[4 * g + 1]));
+                o.z = sqrtf((float)(qn + tn.z - 2 * acc[4 * g + 2]));
+                o.w = sqrtf((float)(qn + tn.w - 2 * acc[4 * g + 3]));
+                if (qrow < nq) {
+                    float* dst = dist + (size_t)qrow * ldd + tg;
+                    if (vec_ok && tg + 3 < nt) {
+                        *(float4*)dst = o;
+                    } else {
+                        if (tg + 0 < nt) dst[0] = o.x;
+                        if (tg + 1 < nt) dst[1] = o.y;
+                        if (tg + 2 < nt) dst[2] = o.z;
+                        if (tg + 3 < nt) dst[3] = o.w;
+                    }
+                }
+            }
+        }
+        if (blk + 1 < nblocks) l_store(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32 path (general float descriptors, and re-scoring of rows flagged by the merge).
+// One block handles QR query rows against the trains of one chunk; thread = train row.
+// Accumulation order = OpenCV SSE2 normL2Sqr_ (16 partial sums, mul then add, no FMA), then sqrtf (rn).
+// key = (float bits of the distance << 32) | train index.
+// row_list == nullptr: rows are blockIdx.x*QR + r.  Otherwise rows come from row_list[0..*row_count).
+// ------------------------------------------------------------------------------------------------
+template <int QR, bool ALIGNED, bool STORE_ALL>
+__global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part,
+                                                             const int* __restrict__ row_list, const int* __restrict__ row_count,
+                                                             float* __restrict__ dist_out, size_t ldd)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm_q[];   // QR x dim query rows
+    __shared__ long long red[4][QR][2];
+    const PairDesc pd = pairs[blockIdx.z];
+    const int dim = pd.dim, chunk = blockIdx.y;
+    if (chunk >= pd.nchunks) return;
+    int rows[QR];
+    if (row_list) {
+        const int cnt = row_count[blockIdx.z];
+        if ((int)blockIdx.x * QR >= cnt) return;
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            const int k = blockIdx.x * QR + r;
+            rows[r] = k < cnt ? row_list[pd.list_off + k] : -1;
+        }
+    } else {
+        if ((int)blockIdx.x * QR >= pd.nq) return;
+#pragma unroll
+        for (int r = 0; r < QR; ++r) { const int k = blockIdx.x * QR + r; rows[r] = k < pd.nq ? k : -1; }
+    }
+    const int tid = threadIdx.x;
+    for (int r = 0; r < QR; ++r) {
+        const int row = rows[r] < 0 ? 0 : rows[r];
+        for (int k = tid; k < dim; k += 256) sm_q[r * dim + k] = pd.qf[(size_t)row * pd.ldq + k];
+    }
+    __syncthreads();
+    const int t_begin = chunk * pd.chunk_rows;
+    int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt) t_end = pd.nt;
+
+    long long k1[QR], k2[QR];
+#pragma unroll
+    for (int r = 0; r < QR; ++r) { k1[r] = KEY_INVALID; k2[r] = KEY_INVALID; }
+
+    for (int j = t_begin + tid; j < t_end; j += 256) {
+        const float* b = pd.tf + (size_t)j * pd.ldt;
+        float acc[QR][16];
+#pragma unroll
+        for (int r = 0; r < QR; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+        int k = 0;
+        for (; k <= dim - 16; k += 16) {
+            float bb[16];
+            if (ALIGNED) {
+                const float4 b0 = *(const float4*)(b + k), b1 = *(const float4*)(b + k + 4);
+                const float4 b2 = *(const float4*)(b + k + 8), b3 = *(const float4*)(b + k + 12);
+                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+                bb[8] = b2.x; bb[9] = b2.y; bb[10] = b2.z; bb[11] = b2.w; bb[12] = b3.x; bb[13] = b3.y; bb[14] = b3.z; bb[15] = b3.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bb[i] = b[k + i];
+            }
+#pragma unroll
+            for (int r = 0; r < QR; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float t = sm_q[r * dim + k + i] - bb[i];
+                    const float m = t * t;
+                    acc[r][i] = m + acc[r][i];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            float s[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                s[l] = ((acc[r][l] + acc[r][4 + l]) + acc[r][8 + l]) + acc[r][12 + l];
+            float d = (s[0] + s[2]) + (s[1] + s[3]);
+            for (int kk = k; kk < dim; ++kk) {
+                const float t = sm_q[r * dim + kk] - b[kk];
+                const float m = t * t;
+                d = d + m;
+            }
+            const float dist = sqrtf(d);
+            if (STORE_ALL) {
+                if (rows[r] >= 0) dist_out[(size_t)rows[r] * ldd + j] = dist;
+            } else {
+                const long long key = ((long long)__float_as_int(dist) << 32) | (unsigned int)j;
+                if (key < k2[r]) { if (key < k1[r]) { k2[r] = k1[r]; k1[r] = key; } else k2[r] = key; }
+            }
+        }
+    }
+    if (STORE_ALL) return;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < QR; ++r) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long o1 = shfl_xor_ll(k1[r], off), o2 = shfl_xor_ll(k2[r], off);
+            merge2(k1[r], k2[r], o1, o2);
+        }
+        if (lane == 0) { red[wave][r][0] = k1[r]; red[wave][r][1] = k2[r]; }
+    }
+    __syncthreads();
+    if (tid < QR && rows[tid] >= 0) {
+        long long a1 = red[0][tid][0], a2 = red[0][tid][1];
+        for (int w = 1; w < 4; ++w) merge2(a1, a2, red[w][tid][0], red[w][tid][1]);
+        long long* o = part + 2 * (pd.part_off + (long long)rows[tid] * pd.nchunks + chunk);
+        o[0] = a1; o[1] = a2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hamming2 kNN-2 (cv::NORM_HAMMING2 on CV_8U rows: number of non-zero 2-bit cells of a^b).
+// thread = query row (16 dwords in registers), train rows streamed through the scalar path
+// (wave-uniform address -> s_load), chunked over blockIdx.y.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part)
+{
+    const PairDesc pd = pairs[blockIdx.z];
+    const int chunk = blockIdx.y;
+    if ((int)blockIdx.x * 256 >= pd.nq_pad || chunk >= pd.nchunks) return;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int rrow = row < pd.nq_pad ? row : 0;
+    const uint4* Q = (const uint4*)pd.q;
+    const uint4* T = (const uint4*)pd.t;
+    const uint4 q0 = Q[(size_t)rrow * 4 + 0], q1 = Q[(size_t)rrow * 4 + 1], q2 = Q[(size_t)rrow * 4 + 2], q3 = Q[(size_t)rrow * 4 + 3];
+    const int t_begin = chunk * pd.chunk_rows;
+    int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt) t_end = pd.nt;
+    int best1 = INT_MAX, best2 = INT_MAX;
+#define H2(x, y) __popc((((x) ^ (y)) | (((x) ^ (y)) << 1)) & 0xAAAAAAAAu)
+    for (int j = t_begin; j < t_end; ++j) {
+        const uint4 t0 = T[(size_t)j * 4 + 0], t1 = T[(size_t)j * 4 + 1], t2 = T[(size_t)j * 4 + 2], t3 = T[(size_t)j * 4 + 3];
+        int d = H2(q0.x, t0.x) + H2(q0.y, t0.y) + H2(q0.z, t0.z) + H2(q0.w, t0.w)
+              + H2(q1.x, t1.x) + H2(q1.y, t1.y) + H2(q1.z, t1.z) + H2(q1.w, t1.w)
+              + H2(q2.x, t2.x) + H2(q2.y, t2.y) + H2(q2.z, t2.z) + H2(q2.w, t2.w)
+              + H2(q3.x, t3.x) + H2(q3.y, t3.y) + H2(q3.z, t3.z) + H2(q3.w, t3.w);
+        const int key = (d << 22) | (j - t_begin);
+        const int mx = best1 > key ? best1 : key;
+        best2 = best2 < mx ? best2 : mx;
+        best1 = best1 < key ? best1 : key;
+    }
+#undef H2
+    if (row < pd.nq_pad) {
+        long long k1 = KEY_INVALID, k2 = KEY_INVALID;
+        if (best1 != INT_MAX) k1 = ((long long)(best1 >> 22) << 32) | (unsigned int)(t_begin + (best1 & 0x3fffff));
+        if (best2 != INT_MAX) k2 = ((long long)(best2 >> 22) << 32) | (unsigned int)(t_begin + (best2 & 0x3fffff));
+        long long* o = part + 2 * (pd.part_off + (long long)row * pd.nchunks + chunk);
+        o[0] = k1; o[1] = k2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of the per-chunk partial top-2 into idx2 / dist2.
+// MODE 0: keys hold integer d^2 (int8 path): dist = sqrtf(float(d^2)); rows with 2nd d^2 >= 2^22 are
+//         appended to the rescore list (their float distances may tie where the integers do not).
+// MODE 1: keys hold float bits (exact path).  MODE 2: keys hold the integer Hamming distance.
+// With row_list != nullptr only the listed rows are merged (after re-scoring).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void merge_kernel(const PairDesc* __restrict__ pairs, const long long* __restrict__ part,
+                             int32_t* __restrict__ idx2, float* __restrict__ dist2,
+                             int* __restrict__ row_list, int* __restrict__ row_count, int use_list)
+{
+    const PairDesc pd = pairs[blockIdx.y];
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (use_list) {
+        if (row >= row_count[blockIdx.y]) return;
+        row = row_list[pd.list_off + row];
+    } else if (row >= pd.nq) return;
+    const long long* p = part + 2 * (pd.part_off + (long long)row * pd.nchunks);
+    long long a1 = p[0], a2 = p[1];
+    for (int c = 1; c < pd.nchunks; ++c) merge2(a1, a2, p[2 * c], p[2 * c + 1]);
+    int i1 = (int)(a1 & 0xffffffffLL), i2 = (int)(a2 & 0xffffffffLL);
+    const int h1 = (int)(a1 >> 32), h2 = (int)(a2 >> 32);
+    const bool v1 = a1 != KEY_INVALID && i1 < pd.nt, v2 = a2 != KEY_INVALID && i2 < pd.nt;
+    float d1, d2;
+    if (MODE == 0) { d1 = sqrtf((float)h1); d2 = sqrtf((float)h2); }
+    else if (MODE == 1) { d1 = __int_as_float(h1); d2 = __int_as_float(h2); }
+    else { d1 = (float)h1; d2 = (float)h2; }
+    const float missing = (MODE == 2) ? 2147483648.0f : FLT_MAX;
+    if (!v1) { i1 = -1; d1 = missing; }
+    if (!v2) { i2 = -1; d2 = missing; }
+    const long long o = pd.out_off + row;
+    idx2[2 * o] = i1; idx2[2 * o + 1] = i2;
+    dist2[2 * o] = d1; dist2[2 * o + 1] = d2;
+    if (MODE == 0 && row_list && v2 && h2 >= RESCORE_D2) {
+        const int k = atomicAdd(&row_count[blockIdx.y], 1);
+        row_list[pd.list_off + k] = row;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ratio tail of match_features on the device (NViewReconstuct.cpp:880-908), one block per pair.
+// fp64 compare for the ratio test, float gate: the same IEEE operations as the host code.
+// Ordered compaction: matches keep query order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ratio_tail_kernel(const PairDesc* __restrict__ pairs,
+                                                          const int32_t* __restrict__ idx2, const float* __restrict__ dist2,
+                                                          double ratio, float floor_, float mult,
+                                                          sfm_dmatch* __restrict__ matches, int max_per_pair, int32_t* __restrict__ counts)
+{
+    __shared__ int s_min;
+    __shared__ int s_wave[16];
+    __shared__ int s_running;
+    const PairDesc pd = pairs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = pd.out_off;
+    if (tid == 0) { s_min = __float_as_int(FLT_MAX); s_running = 0; }
+    __syncthreads();
+    int local = __float_as_int(FLT_MAX);
+    for (int i = tid; i < pd.nq; i += 1024) {
+        if (idx2[2 * (base + i)] < 0 || idx2[2 * (base + i) + 1] < 0) continue;
+        const float d0 = dist2[2 * (base + i)], d1 = dist2[2 * (base + i) + 1];
+        if ((double)d0 > ratio * (double)d1) continue;
+        const int b = __float_as_int(d0);      // d0 >= 0: integer order == float order
+        local = b < local ? b : local;
+    }
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(local, off); local = o < local ? o : local; }
+    if (lane == 0) atomicMin(&s_min, local);
+    __syncthreads();
+    const float min_dist = __int_as_float(s_min);
+    const float gate = mult * (min_dist > floor_ ? min_dist : floor_);
+    sfm_dmatch* out = matches + (size_t)blockIdx.x * max_per_pair;
+    for (int start = 0; start < pd.nq; start += 1024) {
+        const int i = start + tid;
+        bool keep = false; float d0 = 0.0f; int ti = -1;
+        if (i < pd.nq) {
+            ti = idx2[2 * (base + i)];
+            const int t2 = idx2[2 * (base + i) + 1];
+            d0 = dist2[2 * (base + i)];
+            const float d1 = dist2[2 * (base + i) + 1];
+            keep = ti >= 0 && t2 >= 0 && !((double)d0 > ratio * (double)d1 || d0 > gate);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wave) woff += c; total += c; }
+        const int run = s_running;
+        if (keep) {
+            const int k = run + woff + before;
+            if (k < max_per_pair) { sfm_dmatch m; m.queryIdx = i; m.trainIdx = ti; m.imgIdx = 0; m.distance = d0; out[k] = m; }
+        }
+        __syncthreads();
+        if (tid == 0) s_running = run + total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[blockIdx.x] = s_running < max_per_pair ? s_running : max_per_pair;
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int descset_alloc_common(sfmhip_ctx* ctx, int kind, int rows, int dim, sfmhip_descset** out)
+{
+    sfmhip_descset* s = new sfmhip_descset();
+    s->ctx = ctx; s->kind = kind; s->rows = rows; s->dim = dim;
+    s->rows_pad = round_up(rows > 0 ? rows : 1, 128);
+    *out = s;
+    return SFMHIP_OK;
+}
+
+static int descset_prepare_l2(sfmhip_ctx* ctx, sfmhip_descset* s)
+{
+    s->dim_pad = s->dim <= 32 ? 32 : (s->dim <= 64 ? 64 : round_up(s->dim, 128));   // int8 row bytes: 32, 64 or 128
+    const bool mfma_ok = s->dim_pad <= 128;    // d^2 <= 128*255^2 < 2^23 keeps the packed keys exact
+    if (!mfma_ok) { s->exact_u8 = 0; return SFMHIP_OK; }
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_i8, (size_t)s->rows_pad * s->dim_pad));
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_norm, (size_t)s->rows_pad * sizeof(int32_t)));
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_flag, sizeof(int)));
+    SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
+    const int waves_per_block = 4;
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block)), dim3(64 * waves_per_block), 0, ctx->stream,
+                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    int flag = 0;
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(&flag, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    s->exact_u8 = flag == 0;
+    return SFMHIP_OK;
+}
+
+extern "C" {
+
+int sfmhip_descset_create_l2_dev(sfmhip_ctx* ctx, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out);
+    SFM_ARG_CHECK(ctx, d_desc && rows >= 0 && dim > 0 && ld >= (size_t)dim);
+    sfmhip_descset* s = nullptr;
+    descset_alloc_common(ctx, SFMHIP_DESC_L2_F32, rows, dim, &s);
+    s->d_f32 = d_desc; s->ld = ld; s->owns_f32 = false;
+    const int rc = descset_prepare_l2(ctx, s);
+    if (rc != SFMHIP_OK) { sfmhip_descset_destroy(s); return rc; }
+    *out = s;
+    return SFMHIP_OK;
+}
+
+int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out);
+    SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && dim > 0 && ld >= (size_t)dim);
+    float* d = nullptr;
+    const size_t nrow = rows > 0 ? rows : 1;
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&d, nrow * dim * sizeof(float)));
+    if (rows > 0) {
+        hipError_t e = hipMemcpy2DAsync(d, dim * sizeof(float), desc, ld * sizeof(float), dim * sizeof(float), rows,
+                                        hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+    }
+    sfmhip_descset* s = nullptr;
+    descset_alloc_common(ctx, SFMHIP_DESC_L2_F32, rows, dim, &s);
+    s->d_f32 = d; s->ld = dim; s->owns_f32 = true;
+    const int rc = descset_prepare_l2(ctx, s);
+    if (rc != SFMHIP_OK) { sfmhip_descset_destroy(s); return rc; }
+    *out = s;
+    return SFMHIP_OK;
+}
+
+static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uint8_t* d_src, size_t ld)
+{
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_u32, (size_t)s->rows_pad * 64));
+    const size_t n = (size_t)s->rows_pad * 64;
+    hipLaunchKernelGGL(prep_hamming_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_src, ld, s->rows, s->dim, (uint8_t*)s->d_u32, s->rows_pad);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
+int sfmhip_descset_create_hamming2_dev(sfmhip_ctx* ctx, const uint8_t* d_desc, int rows, int nbytes, size_t ld, sfmhip_descset** out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out);
+    SFM_ARG_CHECK(ctx, d_desc && rows >= 0 && nbytes > 0 && nbytes <= 64 && ld >= (size_t)nbytes);
+    sfmhip_descset* s = nullptr;
+    descset_alloc_common(ctx, SFMHIP_DESC_HAMMING2_U8, rows, nbytes, &s);
+    const int rc = descset_prepare_hamming(ctx, s, d_desc, ld);
+    if (rc != SFMHIP_OK) { sfmhip_descset_destroy(s); return rc; }
+    *out = s;
+    return SFMHIP_OK;
+}
+
+int sfmhip_descset_create_hamming2_host(sfmhip_ctx* ctx, const uint8_t* desc, int rows, int nbytes, size_t ld, sfmhip_descset** out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out);
+    SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && nbytes > 0 && nbytes <= 64 && ld >= (size_t)nbytes);
+    uint8_t* d = nullptr;
+    const size_t nrow = rows > 0 ? rows : 1;
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&d, nrow * nbytes));
+    if (rows > 0) {
+        hipError_t e = hipMemcpy2DAsync(d, nbytes, desc, ld, nbytes, rows, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+    }
+    sfmhip_descset* s = nullptr;
+    descset_alloc_common(ctx, SFMHIP_DESC_HAMMING2_U8, rows, nbytes, &s);
+    int rc = descset_prepare_hamming(ctx, s, d, nbytes);
+    if (rc == SFMHIP_OK) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = SFMHIP_E_HIP; }
+    (void)hipFree(d);
+    if (rc != SFMHIP_OK) { sfmhip_descset_destroy(s); return rc; }
+    *out = s;
+    return SFMHIP_OK;
+}
+
+void sfmhip_descset_destroy(sfmhip_descset* s)
+{
+    if (!s) return;
+    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->owns_f32 && s->d_f32) (void)hipFree((void*)s->d_f32);
+    if (s->d_i8) (void)hipFree(s->d_i8);
+    if (s->d_norm) (void)hipFree(s->d_norm);
+    if (s->d_u32) (void)hipFree(s->d_u32);
+    if (s->d_flag) (void)hipFree(s->d_flag);
+    delete s;
+}
+
+int sfmhip_descset_info(sfmhip_descset* s, int* kind, int* rows, int* dim, int* exact_u8)
+{
+    if (!s) return SFMHIP_E_ARG;
+    if (kind) *kind = s->kind;
+    if (rows) *rows = s->rows;
+    if (dim) *dim = s->dim;
+    if (exact_u8) *exact_u8 = s->exact_u8;
+    return SFMHIP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// batched kNN-2 driver
+// ------------------------------------------------------------------------------------------------
+struct KnnPlan {
+    std::vector<PairDesc> pd;
+    long long part_entries = 0, list_entries = 0, out_rows = 0;
+    int max_qpad = 0, max_chunks = 0, max_nq = 0;
+    int path = 0;    // 1 exact f32, 2 int8 mfma, 3 hamming
+    int ks = 0, dim = 0;
+    bool aligned = true;
+};
+
+static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, const int32_t* pairs, int n_pairs,
+                      int force_path, KnnPlan& P)
+{
+    SFM_ARG_CHECK(ctx, sets && pairs && n_pairs > 0 && n_sets > 0);
+    bool all_exact = true; int kind = 0, dim = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = pairs[2 * p], b = pairs[2 * p + 1];
+        SFM_ARG_CHECK(ctx, a >= 0 && a < n_sets && b >= 0 && b < n_sets && sets[a] && sets[b]);
+        const sfmhip_descset* q = sets[a]; const sfmhip_descset* t = sets[b];
+        if (p == 0) { kind = q->kind; dim = q->dim; }
+        SFM_ARG_CHECK(ctx, q->kind == kind && t->kind == kind && q->dim == dim && t->dim == dim);
+        all_exact = all_exact && q->exact_u8 && t->exact_u8;
+    }
+    P.dim = dim;
+    if (kind == SFMHIP_DESC_HAMMING2_U8) P.path = 3;
+    else {
+        if (force_path == 2) { SFM_ARG_CHECK(ctx, all_exact); P.path = 2; }
+        else if (force_path == 1) P.path = 1;
+        else P.path = all_exact ? 2 : 1;
+        P.ks = sets[pairs[0]]->dim_pad / 32;
+    }
+    // chunking: enough workgroups to fill the chip, chunks of whole 128-row blocks, <= 4096 rows (7-bit tile index)
+    long long qblocks_total = 0;
+    const int qgran = (P.path == 3) ? 256 : (P.path == 1 ? 4 : 128);
+    for (int p = 0; p < n_pairs; ++p) qblocks_total += ceil_div(sets[pairs[2 * p]]->rows_pad, qgran);
+    const long long target_wgs = 4LL * ctx->num_cus;
+    P.pd.resize(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const sfmhip_descset* q = sets[pairs[2 * p]]; const sfmhip_descset* t = sets[pairs[2 * p + 1]];
+        PairDesc& d = P.pd[p];
+        memset(&d, 0, sizeof d);
+        d.nq = q->rows; d.nt = t->rows; d.nq_pad = q->rows_pad; d.nt_pad = t->rows_pad; d.dim = dim;
+        if (P.path == 3) { d.q = q->d_u32; d.t = t->d_u32; }
+        else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
+        const int tblocks = d.nt_pad / 128;
+        int nch = (int)((target_wgs + qblocks_total - 1) / (qblocks_total > 0 ? qblocks_total : 1));
+        if (P.path == 1) nch = 1 > nch ? 1 : (nch > 8 ? 8 : nch);
+        if (nch < 1) nch = 1;
+        if (nch > tblocks) nch = tblocks;
+        int cb = ceil_div(tblocks, nch);
+        if (cb > 32) cb = 32;                       // <= 4096 train rows per chunk
+        nch = ceil_div(tblocks, cb);
+        d.nchunks = nch; d.chunk_rows = cb * 128;
+        d.part_off = P.part_entries; P.part_entries += (long long)d.nq_pad * nch;
+        d.out_off = P.out_rows; P.out_rows += d.nq;
+        d.list_off = P.list_entries; P.list_entries += d.nq > 0 ? d.nq : 1;
+        if (d.nq_pad > P.max_qpad) P.max_qpad = d.nq_pad;
+        if (d.nq > P.max_nq) P.max_nq = d.nq;
+        if (nch > P.max_chunks) P.max_chunks = nch;
+        if (P.path != 3) {
+            if ((d.ldq % 4) || (d.ldt % 4) || ((uintptr_t)d.qf % 16) || ((uintptr_t)d.tf % 16)) P.aligned = false;
+        }
+    }
+    return SFMHIP_OK;
+}
+
+struct KnnWork { PairDesc* d_pd; long long* d_part; int* d_list; int* d_count; };
+
+static int knn_workspace(sfmhip_ctx* ctx, const KnnPlan& P, int n_pairs, KnnWork& W)
+{
+    const size_t b_pd = (sizeof(PairDesc) * n_pairs + 255) / 256 * 256;
+    const size_t b_part = ((size_t)P.part_entries * 16 + 255) / 256 * 256;
+    const size_t b_list = ((size_t)P.list_entries * 4 + 255) / 256 * 256;
+    const size_t b_cnt = ((size_t)n_pairs * 4 + 255) / 256 * 256;
+    void* base = nullptr;
+    int rc = sfm_scratch(ctx, b_pd + b_part + b_list + b_cnt, &base);
+    if (rc != SFMHIP_OK) return rc;
+    char* p = (char*)base;
+    W.d_pd = (PairDesc*)p; p += b_pd;
+    W.d_part = (long long*)p; p += b_part;
+    W.d_list = (int*)p; p += b_list;
+    W.d_count = (int*)p;
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(W.d_pd, P.pd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemsetAsync(W.d_count, 0, b_cnt, ctx->stream));
+    return SFMHIP_OK;
+}
+
+template <bool ALIGNED>
+static void launch_exact(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& W, int n_pairs, bool use_list)
+{
+    constexpr int QR = 4;
+    const dim3 grid(ceil_div(P.max_nq > 0 ? P.max_nq : 1, QR), P.max_chunks, n_pairs);
+    const size_t shm = (size_t)QR * P.dim * sizeof(float);
+    hipLaunchKernelGGL((knn2_exact_f32_kernel<QR, ALIGNED, false>), grid, dim3(256), shm, ctx->stream,
+                       W.d_pd, W.d_part, use_list ? W.d_list : (const int*)nullptr, W.d_count, (float*)nullptr, (size_t)0);
+}
+
+// enqueue the kNN-2 of all pairs; results in d_idx2 / d_dist2 (rows concatenated in pair order)
+static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& W, int n_pairs, int32_t* d_idx2, float* d_dist2)
+{
+    if (P.max_nq == 0) return SFMHIP_OK;
+    const dim3 mgrid(ceil_div(P.max_nq, 256), n_pairs);
+    if (P.path == 2) {
+        const dim3 grid(P.max_qpad / 128, P.max_chunks, n_pairs);
+        switch (P.ks) {
+            case 1: hipLaunchKernelGGL(knn2_i8_kernel<1>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
+            case 2: hipLaunchKernelGGL(knn2_i8_kernel<2>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
+            case 4: hipLaunchKernelGGL(knn2_i8_kernel<4>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
+            default: ctx->last_error = "int8 path: dim > 128"; return SFMHIP_E_ARG;
+        }
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(merge_kernel<0>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, W.d_list, W.d_count, 0);
+        // rows whose float distances may tie although the integers differ: exact re-score (normally none)
+        if (P.aligned) launch_exact<true>(ctx, P, W, n_pairs, true); else launch_exact<false>(ctx, P, W, n_pairs, true);
+        hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, W.d_list, W.d_count, 1);
+    } else if (P.path == 1) {
+        if (P.aligned) launch_exact<true>(ctx, P, W, n_pairs, false); else launch_exact<false>(ctx, P, W, n_pairs, false);
+        hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
+    } else {
+        const dim3 grid(ceil_div(P.max_qpad, 256), P.max_chunks, n_pairs);
+        hipLaunchKernelGGL(knn2_hamming2_kernel, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part);
+        hipLaunchKernelGGL(merge_kernel<2>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
+    }
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
+extern "C" {
+
+int sfmhip_knn2_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, const sfmhip_descset* train,
+                    int32_t* d_idx2, float* d_dist2, int force_path)
+{
+    SFM_ARG_CHECK(ctx, ctx && query && train && d_idx2 && d_dist2);
+    sfmhip_descset* sets[2] = { (sfmhip_descset*)query, (sfmhip_descset*)train };
+    const int32_t pr[2] = { 0, 1 };
+    KnnPlan P; KnnWork W;
+    int rc = plan_pairs(ctx, sets, 2, pr, 1, force_path, P); if (rc) return rc;
+    rc = knn_workspace(ctx, P, 1, W); if (rc) return rc;
+    return knn2_pairs_enqueue(ctx, P, W, 1, d_idx2, d_dist2);
+}
+
+int sfmhip_match_pairs_dev(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets,
+                           const int32_t* pairs, int n_pairs, double ratio, float floor_, float mult,
+                           sfm_dmatch* d_matches, int max_per_pair, int32_t* d_counts)
+{
+    SFM_ARG_CHECK(ctx, ctx && d_matches && d_counts && max_per_pair > 0);
+    if (n_pairs == 0) return SFMHIP_OK;
+    KnnPlan P; KnnWork W;
+    int rc = plan_pairs(ctx, sets, n_sets, pairs, n_pairs, 0, P); if (rc) return rc;
+    SFM_ARG_CHECK(ctx, max_per_pair >= P.max_nq);
+    rc = knn_workspace(ctx, P, n_pairs, W); if (rc) return rc;
+    void* tmp = nullptr;
+    const size_t rows = (size_t)(P.out_rows > 0 ? P.out_rows : 1);
+    rc = sfm_scratch2(ctx, rows * 16, &tmp); if (rc) return rc;
+    int32_t* d_idx2 = (int32_t*)tmp; float* d_dist2 = (float*)((char*)tmp + rows * 8);
+    rc = knn2_pairs_enqueue(ctx, P, W, n_pairs, d_idx2, d_dist2); if (rc) return rc;
+    hipLaunchKernelGGL(ratio_tail_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, W.d_pd, d_idx2, d_dist2,
+                       ratio, floor_, mult, d_matches, max_per_pair, d_counts);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
+int sfmhip_match_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets,
+                       const int32_t* pairs, int n_pairs, double ratio, float floor_, float mult,
+                       sfm_dmatch* matches_out, int max_per_pair, int32_t* counts_out)
+{
+    SFM_ARG_CHECK(ctx, ctx && matches_out && counts_out && max_per_pair > 0 && n_pairs >= 0);
+    if (n_pairs == 0) return SFMHIP_OK;
+    sfm_dmatch* d_m = nullptr; int32_t* d_c = nullptr;
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&d_m, (size_t)n_pairs * max_per_pair * sizeof(sfm_dmatch)));
+    hipError_t e = hipMalloc((void**)&d_c, (size_t)n_pairs * sizeof(int32_t));
+    if (e != hipSuccess) { (void)hipFree(d_m); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+    int rc = sfmhip_match_pairs_dev(ctx, sets, n_sets, pairs, n_pairs, ratio, floor_, mult, d_m, max_per_pair, d_c);
+    if (rc == SFMHIP_OK) {
+        e = hipMemcpyAsync(counts_out, d_c, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (int p = 0; p < n_pairs && e == hipSuccess; ++p)
+            if (counts_out[p] > 0)
+                e = hipMemcpyAsync(matches_out + (size_t)p * max_per_pair, d_m + (size_t)p * max_per_pair,
+                                   (size_t)counts_out[p] * sizeof(sfm_dmatch), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
+    }
+    (void)hipFree(d_m); (void)hipFree(d_c);
+    return rc;
+}
+
+static int knn2_host_common(sfmhip_ctx* ctx, sfmhip_descset* qs, sfmhip_descset* ts, int nq, int32_t* idx2, float* dist2)
+{
+    int32_t* d_idx = nullptr; float* d_dist = nullptr;
+    const size_t n = nq > 0 ? nq : 1;
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&d_idx, n * 8));
+    hipError_t e = hipMalloc((void**)&d_dist, n * 8);
+    if (e != hipSuccess) { (void)hipFree(d_idx); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+    int rc = sfmhip_knn2_dev(ctx, qs, ts, d_idx, d_dist, 0);
+    if (rc == SFMHIP_OK && nq > 0) {
+        e = hipMemcpyAsync(idx2, d_idx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dist2, d_dist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
+    }
+    (void)hipFree(d_idx); (void)hipFree(d_dist);
+    return rc;
+}
+
+int sfmhip_knn2_l2_f32(sfmhip_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
+                       size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
+{
+    SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
+    sfmhip_descset *qs = nullptr, *ts = nullptr;
+    int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
+    rc = sfmhip_descset_create_l2_host(ctx, t, nt, dim, ldt, &ts);
+    if (rc == SFMHIP_OK) rc = knn2_host_common(ctx, qs, ts, nq, idx2, dist2);
+    sfmhip_descset_destroy(qs); sfmhip_descset_destroy(ts);
+    return rc;
+}
+
+int sfmhip_knn2_hamming2_u8(sfmhip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
+                            size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
+{
+    SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
+    sfmhip_descset *qs = nullptr, *ts = nullptr;
+    int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
+    rc = sfmhip_descset_create_hamming2_host(ctx, t, nt, nbytes, ldt, &ts);
+    if (rc == SFMHIP_OK) rc = knn2_host_common(ctx, qs, ts, nq, idx2, dist2);
+    sfmhip_descset_destroy(qs); sfmhip_descset_destroy(ts);
+    return rc;
+}
+
+static int match_features_common(sfmhip_ctx* ctx, sfmhip_descset* qs, sfmhip_descset* ts, int nq, sfm_dmatch* out, int* n_out)
+{
+    sfmhip_descset* sets[2] = { qs, ts };
+    const int32_t pr[2] = { 0, 1 };
+    int32_t cnt = 0;
+    if (nq == 0) { *n_out = 0; return SFMHIP_OK; }
+    // NViewReconstuct.cpp:884,900-901: ratio 0.6 (double), gate 5 * max(min_dist, 10.0f)
+    const int rc = sfmhip_match_pairs(ctx, sets, 2, pr, 1, 0.6, 10.0f, 5.0f, out, nq, &cnt);
+    *n_out = cnt;
+    return rc;
+}
+
+int sfmhip_match_features_l2(sfmhip_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
+                             size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
+    sfmhip_descset *qs = nullptr, *ts = nullptr;
+    int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
+    rc = sfmhip_descset_create_l2_host(ctx, t, nt, dim, ldt, &ts);
+    if (rc == SFMHIP_OK) rc = match_features_common(ctx, qs, ts, nq, out, n_out);
+    sfmhip_descset_destroy(qs); sfmhip_descset_destroy(ts);
+    return rc;
+}
+
+int sfmhip_match_features_hamming2(sfmhip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
+                                   size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
+{
+    SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
+    sfmhip_descset *qs = nullptr, *ts = nullptr;
+    int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
+    rc = sfmhip_descset_create_hamming2_host(ctx, t, nt, nbytes, ldt, &ts);
+    if (rc == SFMHIP_OK) rc = match_features_common(ctx, qs, ts, nq, out, n_out);
+    sfmhip_descset_destroy(qs); sfmhip_descset_destroy(ts);
+    return rc;
+}
+
+int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, const sfmhip_descset* train,
+                                  float* d_dist, size_t ld, int force_path)
+{
+    SFM_ARG_CHECK(ctx, ctx && query && train && d_dist);
+    SFM_ARG_CHECK(ctx, query->kind == SFMHIP_DESC_L2_F32 && train->kind == SFMHIP_DESC_L2_F32 && query->dim == train->dim);
+    SFM_ARG_CHECK(ctx, ld >= (size_t)train->rows);
+    if (query->rows == 0 || train->rows == 0) return SFMHIP_OK;
+    const bool exact = query->exact_u8 && train->exact_u8;
+    SFM_ARG_CHECK(ctx, !(force_path == 2 && !exact));
+    if (exact && force_path != 1) {
+        const int bpw = 4;   // 4 x 128 trains per workgroup
+        const dim3 grid(query->rows_pad / 128, ceil_div(train->rows_pad / 128, bpw));
+        const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
+        const int ks = query->dim_pad / 32;
+#define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
+                                        train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok)
+        if (ks == 1) DM_LAUNCH(1); else if (ks == 2) DM_LAUNCH(2); else DM_LAUNCH(4);
+#undef DM_LAUNCH
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        return SFMHIP_OK;
+    }
+    // exact fp32 path, all distances stored
+    sfmhip_descset* sets[2] = { (sfmhip_descset*)query, (sfmhip_descset*)train };
+    const int32_t pr[2] = { 0, 1 };
+    KnnPlan P; KnnWork W;
+    int rc = plan_pairs(ctx, sets, 2, pr, 1, 1, P); if (rc) return rc;
+    rc = knn_workspace(ctx, P, 1, W); if (rc) return rc;
+    constexpr int QR = 4;
+    const dim3 grid(ceil_div(P.max_nq, QR), P.max_chunks, 1);
+    const size_t shm = (size_t)QR * P.dim * sizeof(float);
+    if (P.aligned)
+        hipLaunchKernelGGL((knn2_exact_f32_kernel<QR, true, true>), grid, dim3(256), shm, ctx->stream, W.d_pd, W.d_part,
+                           (const int*)nullptr, W.d_count, d_dist, ld);
+    else
+        hipLaunchKernelGGL((knn2_exact_f32_kernel<QR, false, true>), grid, dim3(256), shm, ctx->stream, W.d_pd, W.d_part,
+                           (const int*)nullptr, W.d_count, d_dist, ld);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+"""GPU parity of the matching path vs the CPU oracle (bit-exact index sets, bit-exact float distances).
+Everything goes through the C-ABI (sfm_opencv_amd.api -> libsfmhip.so)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from sfm_opencv_amd import synth
+from sfm_opencv_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_knn(ctx, q, t, hamming=False):
+    if hamming:
+        gi, gd = ctx.knn2_hamming2(q, t); oi, od = orc.knn2_hamming2(q, t)
+    else:
+        gi, gd = ctx.knn2_l2(q, t); oi, od = orc.knn2_l2(q, t)
+    assert np.array_equal(gi, oi), f"index mismatch at rows {np.nonzero((gi != oi).any(1))[0][:10]}"
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (5, 3), (128, 128), (129, 255), (300, 1000), (2000, 2000), (513, 4500)])
+def test_knn2_l2_sift_like_int8_path(ctx, nq, nt):
+    d = synth.sift_descriptor_chain(2, max(nq, nt), seed=11 + nq)
+    q, t = d[0][:nq], d[1][:nt]
+    s = ctx.descset_l2(q)
+    assert s.info()["exact_u8"]
+    _check_knn(ctx, q, t)
+
+
+def test_knn2_l2_many_exact_ties(ctx):
+    # few distinct values -> many equal distances: lowest train index must win, as cv::batchDistance does
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 3, (257, 128)).astype(np.float32)
+    t = np.repeat(rng.integers(0, 3, (40, 128)), 8, axis=0).astype(np.float32)   # every train row 8 times
+    _check_knn(ctx, q, t)
+
+
+def _three_squares(n):
+    for a in range(int(n ** 0.5), -1, -1):
+        for b in range(int((n - a * a) ** 0.5), -1, -1):
+            c2 = n - a * a - b * b
+            c = int(round(c2 ** 0.5))
+            if c * c == c2 and max(a, b, c) <= 255:
+                return a, b, c
+    return None
+
+
+def test_knn2_l2_sqrt_collision_rescore(ctx):
+    # d^2 >= 2^22: distinct integers can share one float32 sqrt; cv::batchDistance compares the float32 distances,
+    # so the LOWER train index wins although its integer distance is larger.  Forces the flagged-row re-score branch.
+    base = 125 * 200 * 200                      # 5,000,000 >= 2^22
+    k = next(k for k in range(1, 5000)
+             if np.sqrt(np.float32(base + k)) == np.sqrt(np.float32(base + k + 1))
+             and _three_squares(k) and _three_squares(k + 1))
+    rng = np.random.default_rng(5)
+    t = rng.integers(230, 256, (300, 128)).astype(np.float32)     # far away from the zero query rows
+    t[0, :125] = 200; t[0, 125:] = _three_squares(k + 1)          # index 0: d^2 = base + k + 1 (larger integer)
+    t[1, :125] = 200; t[1, 125:] = _three_squares(k)              # index 1: d^2 = base + k     (smaller integer)
+    q = np.zeros((130, 128), np.float32)
+    q[1:] = rng.integers(0, 3, (129, 128))
+    oi, od = orc.knn2_l2(q, t)
+    assert oi[0, 0] == 0 and oi[0, 1] == 1 and od[0, 0] == od[0, 1]   # float tie -> lower index first
+    d2 = ((q[0].astype(np.int64) - t.astype(np.int64)) ** 2).sum(-1)
+    assert d2[1] < d2[0] and d2[1] >= 2 ** 22                          # integer order would say index 1
+    _check_knn(ctx, q, t)
+
+
+@pytest.mark.parametrize("dim", [128, 64, 40, 20])
+def test_knn2_l2_general_float_exact_path(ctx, dim):
+    rng = np.random.default_rng(7 + dim)
+    q = rng.standard_normal((70, dim)).astype(np.float32) * 50
+    t = rng.standard_normal((333, dim)).astype(np.float32) * 50
+    assert not ctx.descset_l2(q).info()["exact_u8"]
+    _check_knn(ctx, q, t)
+
+
+@pytest.mark.parametrize("dim", [32, 64, 100])
+def test_knn2_l2_small_dims_int8_path(ctx, dim):
+    rng = np.random.default_rng(dim)
+    q = rng.integers(0, 256, (200, dim)).astype(np.float32)
+    t = rng.integers(0, 256, (300, dim)).astype(np.float32)
+    _check_knn(ctx, q, t)
+
+
+def test_knn2_l2_fewer_than_two_trains(ctx):
+    rng = np.random.default_rng(9)
+    q = rng.integers(0, 256, (10, 128)).astype(np.float32)
+    t = rng.integers(0, 256, (1, 128)).astype(np.float32)
+    gi, gd = ctx.knn2_l2(q, t)
+    oi, od = orc.knn2_l2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert (gi[:, 1] == -1).all()
+
+
+@pytest.mark.parametrize("nq,nt,nb", [(3, 2, 61), (256, 257, 61), (1000, 3000, 61), (100, 100, 32), (77, 500, 64)])
+def test_knn2_hamming2(ctx, nq, nt, nb):
+    d = synth.akaze_descriptor_chain(2, max(nq, nt), nbytes=nb, seed=nq)
+    _check_knn(ctx, d[0][:nq], d[1][:nt], hamming=True)
+
+
+def test_match_features_l2_and_chain(ctx):
+    descs = synth.sift_descriptor_chain(4, 700, seed=21)
+    got = api.match_features_for_all(descs, ctx=ctx)
+    assert len(got) == 3
+    for i, g in enumerate(got):
+        ref = orc.match_features_l2(descs[i], descs[i + 1])
+        assert len(ref) > 100
+        assert np.array_equal(g, ref)          # structured compare: ids and float distance bits
+    one = api.match_features(descs[0], descs[1], ctx=ctx)
+    assert np.array_equal(one, orc.match_features_l2(descs[0], descs[1]))
+
+
+def test_match_features_hamming2_chain_with_ragged_sizes(ctx):
+    descs = synth.akaze_descriptor_chain(3, 900, seed=2)
+    descs = [descs[0][:500], descs[1], descs[2][:130]]
+    got = api.match_features_for_all(descs, ctx=ctx)
+    for i, g in enumerate(got):
+        ref = orc.match_features_hamming2(descs[i], descs[i + 1])
+        assert np.array_equal(g, ref)
+
+
+def test_ratio_tail_device_equals_host(ctx):
+    descs = synth.sift_descriptor_chain(2, 1500, seed=33)
+    idx, dist = ctx.knn2_l2(descs[0], descs[1])
+    host = api.ratio_filter(idx, dist)
+    dev = api.match_features(descs[0], descs[1], ctx=ctx)
+    assert np.array_equal(host, dev)
+    assert np.array_equal(host, orc.ratio_filter(idx, dist))
+
+
+def test_distance_matrix(ctx):
+    import torch
+    descs = synth.sift_descriptor_chain(2, 600, seed=44)
+    q, t = descs[0][:333], descs[1][:590]
+    qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
+    for ld in (592, 591):     # vector and scalar store paths
+        out = torch.full((333, ld), -1.0, device="cuda", dtype=torch.float32)
+        ctx.l2_distance_matrix_dev(qs, ts, out)
+        ctx.synchronize()
+        ref = orc.l2_distance_matrix(q, t)
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :590].view(np.uint32), ref.view(np.uint32))
+        assert (got[:, 590:] == -1.0).all()
+    # general float inputs: exact path
+    rng = np.random.default_rng(1)
+    qf = rng.standard_normal((50, 128)).astype(np.float32); tf = rng.standard_normal((90, 128)).astype(np.float32)
+    out = torch.zeros((50, 90), device="cuda", dtype=torch.float32)
+    ctx.l2_distance_matrix_dev(ctx.descset_l2(qf), ctx.descset_l2(tf), out)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), orc.l2_distance_matrix(qf, tf).view(np.uint32))
+
+
+def test_device_resident_knn_and_forced_paths_agree(ctx):
+    import torch
+    descs = synth.sift_descriptor_chain(2, 1100, seed=55)
+    q = torch.from_numpy(descs[0]).cuda(); t = torch.from_numpy(descs[1]).cuda()
+    qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
+    res = []
+    for path in (2, 1):
+        idx = torch.empty((1100, 2), dtype=torch.int32, device="cuda")
+        dist = torch.empty((1100, 2), dtype=torch.float32, device="cuda")
+        ctx.knn2_dev(qs, ts, idx, dist, force_path=path)
+        ctx.synchronize()
+        res.append((idx.cpu().numpy(), dist.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    oi, od = orc.knn2_l2(descs[0], descs[1])
+    assert np.array_equal(res[0][0], oi) and np.array_equal(res[0][1], od)
