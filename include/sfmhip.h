@@ -202,7 +202,8 @@ void sfmhip_ba_destroy(sfmhip_ba*);
  * ranks, ordered on `hip_stream`; return 0 on success.  (RCCL: ncclAllReduce(d_buf,d_buf,count,
  * ncclDouble,ncclSum,comm,stream); torch.distributed: dist.all_reduce on a tensor view.) */
 typedef int (*sfmhip_allreduce_fn)(void* user, void* d_buf, size_t count, void* hip_stream);
-int  sfmhip_ba_set_allreduce(sfmhip_ba*, sfmhip_allreduce_fn fn, void* user);
+/* rank / world: this process's index and the number of ranks (<= 64); resets the LM state. */
+int  sfmhip_ba_set_allreduce(sfmhip_ba*, sfmhip_allreduce_fn fn, void* user, int rank, int world);
 /* run the LM loop to termination */
 int  sfmhip_ba_run(sfmhip_ba*, sfm_ba_summary* summary);
 /* run exactly n_iter LM iterations (tolerance checks disabled); state carries over between calls */
@@ -212,7 +213,8 @@ int  sfmhip_ba_reset(sfmhip_ba*);
 int  sfmhip_ba_get_params(sfmhip_ba*, double* intrinsic4, double* ext6, double* pts);
 /* Test/diagnostic: linearise at the current parameters with trust-region radius `radius` and copy
  * out the reduced camera system (order n = 6*(n_cam - fixed) + 4*(!fix_intrinsics); S row-major n x n,
- * lower triangle valid; rhs n) after the all-reduce.  Either pointer may be NULL. */
+ * both triangles filled; rhs n) after the all-reduce.  Either pointer may be NULL.  radius < 0: the points are
+ * damped with |radius| but the camera-side damping is skipped, so the result is additive over point shards. */
 int  sfmhip_ba_reduced_system(sfmhip_ba*, double radius, double* S, double* rhs, int* n, double* cost);
 /* average device time (ms) of the phases of the last sfmhip_ba_iterate call, measured with HIP events on
  * the context's stream: [0]=linearise+Schur build, [1]=reduced solve, [2]=back-substitution+cost, [3]=total */

@@ -104,7 +104,7 @@ def load():
         "sfmhip_ba_solve": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(BAOptions), C.POINTER(BASummary)]),
         "sfmhip_ba_create": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(BAOptions), C.POINTER(vp)]),
         "sfmhip_ba_destroy": (None, [vp]),
-        "sfmhip_ba_set_allreduce": (i32, [vp, ALLREDUCE_FN, vp]),
+        "sfmhip_ba_set_allreduce": (i32, [vp, ALLREDUCE_FN, vp, i32, i32]),
         "sfmhip_ba_run": (i32, [vp, C.POINTER(BASummary)]),
         "sfmhip_ba_iterate": (i32, [vp, i32, C.POINTER(BASummary)]),
         "sfmhip_ba_reset": (i32, [vp]),

@@ -220,7 +220,7 @@ class BAProblem:
         self.h = h
         self._cb = None
 
-    def set_allreduce(self, fn):
+    def set_allreduce(self, fn, rank, world):
         """fn(dev_ptr:int, count:int, stream:int) -> 0 on success; sums `count` doubles in place over all ranks."""
         def _tramp(user, buf, count, stream):
             try:
@@ -230,7 +230,7 @@ class BAProblem:
                 traceback.print_exc()
                 return -1
         self._cb = _lib.ALLREDUCE_FN(_tramp)
-        self.ctx._check(self.ctx.lib.sfmhip_ba_set_allreduce(self.h, self._cb, None))
+        self.ctx._check(self.ctx.lib.sfmhip_ba_set_allreduce(self.h, self._cb, None, int(rank), int(world)))
 
     def run(self):
         s = BASummary()
