@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the matching -> BA hot path on MI355X (BASELINE.json metric:
+"BA iterations/sec + matched-pairs/sec, 200-img/300k-pt scene").
+
+    python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config C4 of BASELINE.json, synthetic): 200 images x 5000 integer-valued SIFT-like descriptors
+(199 chain pairs) and a 200-camera / 300k-point / ~1.2M-observation BA scene.  The scene is FIXED as N grows
+("strong" scaling): pairs and points are sharded over the ranks; BA exchanges one all-reduce per LM iteration.
+
+Timed regions (each: barrier + synchronize on both sides, exactly K steps, MAX over ranks):
+  A (primary, `value`)  K LM iterations (linearise + Schur build + reduced solve + back-substitution + candidate cost),
+                         parameters/observations resident in HBM.
+  B (`matched_pairs_per_sec`) K passes over this rank's chain pairs: descriptor preparation + kNN-2 + ratio tail on
+                         the device, match lists copied to pinned host memory; float descriptors resident in HBM.
+Plus the materialised 10k x 10k x 128 distance matrix (north-star HBM-roofline case) timed with events on the stream.
+Rank 0 prints ONE JSON line.  The CPU baseline is this repo's own C restatement (oracle/, kind "port"), NOT OpenCV/Ceres.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s measured copy
+I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x bf16 dense (~2.5 PFLOP/s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C4", choices=["C3", "C4", "small"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sfm_opencv_amd import synth, api
+    from sfm_opencv_amd import dist as sdist
+
+    rank, world, local = sdist.init_process_group()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    ctx = api.Context(local, use_torch_stream=True)
+    stream = ctx.torch_stream
+
+    cfg = dict(synth.CONFIGS[args.config]) if args.config in synth.CONFIGS else dict(n_img=12, n_desc=1000, n_pt=5000)
+    n_img, n_desc, n_pt = cfg["n_img"], cfg["n_desc"], cfg["n_pt"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ region A: bundle adjustment
+    sc = synth.ba_scene(n_img, n_pt)
+    pts_l, oc_l, op_l, uv_l, _ = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], rank, world)
+    pb = ctx.ba_create(sc["K0"], sc["ext0"], pts_l, oc_l, op_l, uv_l)
+    if world > 1:
+        pb.set_allreduce(sdist.make_allreduce_hook(), rank, world)
+    s0 = pb.iterate(args.warmup) if args.warmup > 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    s1 = pb.iterate(args.steps)
+    barrier()
+    t_ba = max_over_ranks(time.perf_counter() - t0)
+    phase = pb.phase_ms()
+    ba_its = args.steps / t_ba
+    n_red = 6 * (n_img - 1) + 4
+    n_obs = sc["n_obs"]
+    # algorithmic bytes per LM iteration: observation records read by the linearisation and by the
+    # candidate-cost pass, points read + written, cameras, S written + read by the factorisation + factor written
+    b_it = 2 * 24 * n_obs + 2 * 24 * n_pt + 2 * 48 * n_img + 3 * 8 * n_red * n_red
+
+    # ------------------------------------------------------------------ region B: matching
+    pairs_g, images, pairs_l = sdist.shard_pairs(n_img, rank, world)
+    chain = None
+    d_desc, sets = [], []
+    if len(images):
+        # descriptors of image i depend on image i-1: generate the chain up to this rank's last image
+        chain = synth.sift_descriptor_chain(images[-1] + 1, n_desc)
+        for i in images:
+            t = torch.from_numpy(chain[i]).cuda()
+            d_desc.append(t); sets.append(ctx.descset_l2(t))
+    n_pairs_l = pairs_l.shape[0]
+    d_matches = torch.zeros((max(n_pairs_l, 1), n_desc, 4), dtype=torch.int32, device="cuda")
+    d_counts = torch.zeros((max(n_pairs_l, 1),), dtype=torch.int32, device="cuda")
+    h_matches = torch.zeros_like(d_matches, device="cpu").pin_memory()
+    h_counts = torch.zeros_like(d_counts, device="cpu").pin_memory()
+
+    def match_pass():
+        if n_pairs_l == 0:
+            return
+        for s in sets:
+            s.refresh()
+        ctx.match_pairs_dev(sets, pairs_l, d_matches, n_desc, d_counts)
+        h_matches.copy_(d_matches, non_blocking=True)
+        h_counts.copy_(d_counts, non_blocking=True)
+
+    for _ in range(args.warmup):
+        match_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        match_pass()
+    barrier()
+    t_match = max_over_ranks(time.perf_counter() - t0)
+    pairs_per_s = (n_img - 1) * args.steps / t_match
+    n_matches = int(h_counts.sum().item())
+    # kNN-only device time of one pass (events on the stream), for the MFMA roofline of the fused kernel
+    knn_ms = None
+    if n_pairs_l:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            ctx.match_pairs_dev(sets, pairs_l, d_matches, n_desc, d_counts)
+        e1.record(stream); torch.cuda.synchronize()
+        knn_ms = e0.elapsed_time(e1) / 3
+
+    # ------------------------------------------------------------------ materialised 10k x 10k distance matrix
+    gemm = None
+    if not args.no_gemm and rank == 0:
+        nq = nt = 10000
+        dd = synth.sift_descriptor_chain(2, nq, seed=synth.SEED + 100000)
+        q = torch.from_numpy(dd[0]).cuda(); t = torch.from_numpy(dd[1]).cuda()
+        qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
+        out = torch.empty((nq, nt), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            ctx.l2_distance_matrix_dev(qs, ts, out)
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            ctx.l2_distance_matrix_dev(qs, ts, out)
+        e1.record(stream); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg = 4.0 * nq * nt + 4.0 * 128 * (nq + nt)          # 410.2 MB
+        gemm = dict(kernel="distmat_i8_kernel<4>", workload="10000x10000x128 float32 distance matrix", ms=ms,
+                    bound="hbm", achieved=alg / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=alg, traffic=None)
+        del out, qs, ts
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0:
+        import oracle as orc
+        cores = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
+        orc.set_num_threads(cores)
+        n_it_cpu = 3
+        tc = time.perf_counter()
+        orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], force_iterations=n_it_cpu)
+        t_cpu_ba = time.perf_counter() - tc
+        cpu_pairs = 2
+        ch = chain if chain is not None and len(chain) > cpu_pairs else synth.sift_descriptor_chain(cpu_pairs + 1, n_desc)
+        tc = time.perf_counter()
+        for i in range(cpu_pairs):
+            orc.match_features_l2(ch[i], ch[i + 1])
+        t_cpu_m = time.perf_counter() - tc
+        cpu = dict(value=n_it_cpu / t_cpu_ba, unit="it/s", cores=cores, kind="port",
+                   sample=f"{n_it_cpu} forced LM iterations of the same {n_img}-camera/{n_pt}-point scene (incl. one extra "
+                          f"linearisation for the column scaling) and {cpu_pairs} chain pairs of {n_desc}x{n_desc}x128 matching; "
+                          "oracle/ C restatement with OpenMP, not OpenCV/Ceres (unbuildable offline)",
+                   matched_pairs_per_sec=cpu_pairs / t_cpu_m)
+
+    if rank == 0:
+        # dominant kernel of an LM iteration at this size: the reduced-system factorisation (see profiles/)
+        t_solve = phase[1] * 1e-3
+        n_pad = (n_red + 31) // 32 * 32
+        solve_bytes = 3 * 8 * n_pad * n_pad          # S read + factor written + read by the triangular solves
+        out = {
+            "metric": "ba_iterations_per_sec", "value": ba_its, "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_ba / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img - 1} chain pairs), "
+                                   f"{n_img} cameras / {n_pt} points / {n_obs} observations BA",
+                       "parallelism": f"points+pairs sharded over {world} rank(s), cameras replicated, 1 all-reduce/iteration",
+                       "reduced_system_order": n_red},
+            "roofline": {"kernel": "LM iteration (all kernels)", "bound": "hbm", "achieved": b_it / (phase[3] * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_it / (phase[3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": b_it, "device_ms": phase[3]},
+            "ba_phase_ms": {"linearize_schur": phase[0], "reduced_solve": phase[1], "backsub_cost": phase[2], "total_device": phase[3]},
+            "roofline_reduced_solve": {"bound": "hbm", "achieved": solve_bytes / max(t_solve, 1e-12) / 1e9, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": solve_bytes / max(t_solve, 1e-12) / 1e9 / HBM_PEAK_GBS},
+            "ba_cost": {"initial": (s0 or s1)["initial_cost"], "after_timed_steps": s1["final_cost"],
+                        "successful_steps": s1["successful_steps"], "iterations": s1["iterations"]},
+            "matched_pairs_per_sec": {"value": pairs_per_s, "ms_per_pass": 1e3 * t_match / args.steps, "pairs": n_img - 1,
+                                      "matches_rank0": n_matches, "includes": "prep + kNN-2 + ratio tail + D2H of match lists"},
+            "roofline_gemm": gemm,
+            "cpu_baseline": cpu,
+        }
+        if knn_ms:
+            ops = 2.0 * n_desc * n_desc * 128 * n_pairs_l
+            out["roofline_knn"] = {"kernel": "knn2_i8_kernel<4> + merge + ratio tail", "bound": "mfma", "ms_per_pass_rank0": knn_ms,
+                                   "achieved": ops / (knn_ms * 1e-3) / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                                   "frac": ops / (knn_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,8 @@ int sfmhip_descset_create_l2_dev (sfmhip_ctx*, const float* d_desc, int rows, in
 int sfmhip_descset_create_hamming2_host(sfmhip_ctx*, const uint8_t* desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
 int sfmhip_descset_create_hamming2_dev (sfmhip_ctx*, const uint8_t* d_desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
 void sfmhip_descset_destroy(sfmhip_descset*);
+/* re-run the device preparation pass (int8 copy + norms) on the set's float rows; enqueues only */
+int sfmhip_descset_refresh(sfmhip_descset*);
 /* kind = SFMHIP_DESC_*; exact_u8 = 1 when the int8 MFMA path is usable (synchronises) */
 int sfmhip_descset_info(sfmhip_descset*, int* kind, int* rows, int* dim, int* exact_u8);
 

@@ -35,6 +35,9 @@ class DescSet:
         self.ctx._check(self.ctx.lib.sfmhip_descset_info(self.handle, kind, rows, dim, ex))
         return dict(kind=kind.value, rows=rows.value, dim=dim.value, exact_u8=bool(ex.value))
 
+    def refresh(self):
+        self.ctx._check(self.ctx.lib.sfmhip_descset_refresh(self.handle))
+
     def close(self):
         if self.handle and self.ctx.h:      # the context owns the stream: never touch a set after its context died
             self.ctx.lib.sfmhip_descset_destroy(self.handle)
@@ -59,9 +62,17 @@ class Context:
                               "(no usable gfx950 device; there is no CPU fallback)")
         self.h = h
         self.device = device
+        self.torch_stream = None
         if use_torch_stream:
             import torch
-            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            st = torch.cuda.current_stream(device)
+            if st.cuda_stream == 0:
+                # the legacy default stream has handle 0, which the C-ABI reads as "use the context's own stream":
+                # make a real stream current so that torch events / copies / collectives and the library share it
+                st = torch.cuda.Stream(device=device)
+                torch.cuda.set_stream(st)
+            self.torch_stream = st
+            self.set_stream(st.cuda_stream)
 
     def _check(self, rc):
         if rc != 0:

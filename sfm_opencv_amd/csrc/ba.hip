@@ -10,6 +10,7 @@
 // done through the caller's all-reduce hook (RCCL over xGMI in production, gloo in the CPU tests of the host logic).
 #include "common.hpp"
 #include "ba_kernels.hpp"
+#include "ba_solver.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -19,52 +20,32 @@
 // ------------------------------------------------------------------------------------------------
 #define NB 32
 
-__device__ __forceinline__ double readlane_d(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// One wave factors the 32x32 diagonal block k in registers (lane i < 32 owns row i) and writes L_kk and
-// its inverse (row-major 32x32 at Linv + k*1024).  Cross-lane traffic is v_readlane with constant lanes.
+// Dense path, step 1: one wave factors the 32x32 diagonal block k (wave_chol32) and writes L_kk and its inverse
+// (row-major 32x32 at Linv + k*1024).
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, int ld, int k, double* __restrict__ Linv, int* __restrict__ err)
 {
-    const int lane = threadIdx.x;
-    const int row = lane & 31;
-    double a[NB];
+    __shared__ DiagLds s;
+    const int lane = threadIdx.x, row = lane & 31;
     double* base = A + (size_t)(k * NB) * ld + k * NB;
+    if (lane < 32)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = base[(size_t)row * ld + c];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double d = readlane_d(a[j], j);
-        ok = ok && (d > 0.0) && (d < 1e300);
-        d = sqrt(d > 0.0 ? d : 1.0);
-        const double inv = 1.0 / d;
-        a[j] = (row == j) ? d : a[j] * inv;
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= a[j] * readlane_d(a[j], c);
-    }
+        for (int c = 0; c < NB; ++c) s.D[row][c] = base[(size_t)row * ld + c];
+    __syncthreads();
+    const bool ok = wave_chol32(s, lane);
     if (!ok && lane == 0) *err = 2;
-    if (lane < 32) {
+    __syncthreads();
+    if (lane < 32)
 #pragma unroll
-        for (int c = 0; c < NB; ++c) base[(size_t)row * ld + c] = (c <= row) ? a[c] : 0.0;
-    }
-    // X = L^-1, lane = column c: x[i] = (delta_ic - sum_{m<i} L[i][m] x[m]) / L[i][i]
+        for (int c = 0; c < NB; ++c) base[(size_t)row * ld + c] = s.D[row][c];
+    // X = L^-1: row i of X is e_i L^-T ... computed as x L^-T with x = e_row, i.e. lane = row of L^-T = column of L^-1
     double x[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        double s = (row == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int m = 0; m < i; ++m) s -= readlane_d(a[m], i) * x[m];
-        x[i] = s / readlane_d(a[i], i);
-    }
+    for (int m = 0; m < NB; ++m) x[m] = (m == row) ? 1.0 : 0.0;
+    row_trsm32(x, s);                      // x = e_row L^-T  =>  x[c] = (L^-1)[c][row]
     if (lane < 32) {
         double* out = Linv + (size_t)k * NB * NB;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) out[i * NB + row] = (row <= i) ? x[i] : 0.0;
+        for (int i = 0; i < NB; ++i) out[i * NB + row] = x[i];
     }
 }
 
@@ -173,6 +154,8 @@ struct sfmhip_ba {
     // structure
     int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_obs = nullptr;
     int *d_blk_cam = nullptr, *d_blk_start = nullptr, *d_items = nullptr;
+    int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
+    std::vector<int> host_blk_cam;
     double* d_ouv = nullptr;
     // work
     double *d_scale_c = nullptr, *d_scale_p = nullptr, *d_Vinv = nullptr, *d_bp = nullptr, *d_WK = nullptr, *d_colsq_p = nullptr;
@@ -261,6 +244,12 @@ static int enqueue_solve(sfmhip_ba* h)
     hipStream_t st = ctx->stream;
     double* S = h->d_msg;
     const int nb = h->nbk, ld = h->npad;
+    if (h->use_sparse) {
+        double* rhs_rw = h->d_msg + (size_t)h->npad * h->npad;
+        hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, nb, h->d_prow_start, h->d_prow, rhs_rw, h->d_y, h->d_err);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        return SFMHIP_OK;
+    }
     for (int k = 0; k < nb; ++k) {
         hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, st, S, ld, k, h->d_Linv, h->d_err);
         const int m = nb - k - 1;
@@ -287,11 +276,64 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     return call_allreduce(h, h->d_back4, 4);
 }
 
+// Block fill pattern of the reduced system (32x32 blocks) -> per-panel row lists for chol_sparse_kernel.
+// Multi-rank: the pattern is the union over ranks (S is summed), taken through the all-reduce hook.
+static int build_solver_plan(sfmhip_ba* h)
+{
+    sfmhip_ctx* ctx = h->ctx;
+    const int nb = h->nbk;
+    std::vector<double> pat((size_t)nb * nb, 0.0);
+    auto mark = [&](int lo_a, int hi_a, int lo_b, int hi_b) {       // scalar index ranges [lo, hi)
+        for (int i = lo_a / NB; i <= (hi_a - 1) / NB; ++i)
+            for (int j = lo_b / NB; j <= (hi_b - 1) / NB; ++j) { pat[(size_t)i * nb + j] = 1.0; pat[(size_t)j * nb + i] = 1.0; }
+    };
+    for (int i = 0; i < nb; ++i) pat[(size_t)i * nb + i] = 1.0;
+    for (int c = h->fix0; c < h->nc; ++c) {
+        const int co = 6 * (c - h->fix0);
+        mark(co, co + 6, co, co + 6);
+        if (!h->fixK) mark(co, co + 6, h->koff, h->koff + 4);
+    }
+    if (!h->fixK) mark(h->koff, h->koff + 4, h->koff, h->koff + 4);
+    for (size_t b = 0; b + 1 < h->host_blk_cam.size(); b += 2) {
+        const int oa = 6 * (h->host_blk_cam[b] - h->fix0), ob = 6 * (h->host_blk_cam[b + 1] - h->fix0);
+        mark(oa, oa + 6, ob, ob + 6);
+    }
+    if (h->ar_fn) {
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_msg, pat.data(), pat.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int rc = call_allreduce(h, h->d_msg, pat.size()); if (rc) return rc;
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(pat.data(), h->d_msg, pat.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<char> P((size_t)nb * nb, 0);
+    for (int i = 0; i < nb; ++i) for (int j = 0; j <= i; ++j) P[(size_t)i * nb + j] = pat[(size_t)i * nb + j] != 0.0;
+    std::vector<int> start(nb + 1, 0), rows;
+    int maxR = 0;
+    for (int k = 0; k < nb; ++k) {
+        std::vector<int> rk;
+        for (int i = k + 1; i < nb; ++i) if (P[(size_t)i * nb + k]) rk.push_back(i);
+        for (size_t a = 0; a < rk.size(); ++a) for (size_t b = 0; b <= a; ++b) P[(size_t)rk[a] * nb + rk[b]] = 1;
+        maxR = std::max(maxR, (int)rk.size());
+        rows.insert(rows.end(), rk.begin(), rk.end());
+        start[k + 1] = (int)rows.size();
+    }
+    h->max_panel_rows = maxR;
+    h->use_sparse = maxR <= SRMAX && h->npad <= (SRMAX * SNB + 1) * SLD;
+    if (getenv("SFMHIP_DENSE_SOLVER")) h->use_sparse = false;
+    if (h->use_sparse) {
+        if (!h->d_prow_start) { int rc = dalloc(h, &h->d_prow_start, (size_t)nb + 1); if (rc) return rc; rc = dalloc(h, &h->d_prow, (size_t)nb * SRMAX + 1); if (rc) return rc; }
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (!rows.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFMHIP_OK;
+}
+
 // iteration 0 work: jacobi scaling from the column norms at x0, |x0|
 static int ba_start(sfmhip_ba* h)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
+    { int rc = build_solver_plan(h); if (rc) return rc; }
     const size_t np3 = 3 * (size_t)h->np;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->npad + 255) / 256)), dim3(256), 0, st, h->d_scale_c, (size_t)h->npad, 1.0);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((np3 + 255) / 256 + 1)), dim3(256), 0, st, h->d_scale_p, np3, 1.0);
@@ -494,6 +536,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     }
     blk_start.push_back((int)items.size());
     h->nblk = (int)blk_cam.size() / 2;
+    h->host_blk_cam = blk_cam;
 
     int rc = SFMHIP_OK;
 #define TRY_RC(x) do { rc = (x); if (rc) { sfmhip_ba_destroy(h); return rc; } } while (0)

@@ -678,6 +678,19 @@ void sfmhip_descset_destroy(sfmhip_descset* s)
     delete s;
 }
 
+// re-run the preparation pass on the (possibly rewritten) borrowed float rows; asynchronous, keeps exact_u8
+int sfmhip_descset_refresh(sfmhip_descset* s)
+{
+    if (!s || !s->ctx) return SFMHIP_E_ARG;
+    sfmhip_ctx* ctx = s->ctx;
+    if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) return SFMHIP_OK;
+    SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, 4)), dim3(256), 0, ctx->stream,
+                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
 int sfmhip_descset_info(sfmhip_descset* s, int* kind, int* rows, int* dim, int* exact_u8)
 {
     if (!s) return SFMHIP_E_ARG;

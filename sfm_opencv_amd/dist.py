@@ -1,0 +1,94 @@
+"""One process per GPU: sharding of the hot path over ranks and the all-reduce hook.
+
+* matching / triangulation: image pairs are independent (NViewReconstuct.cpp:857-862) -> contiguous blocks of the
+  pair chain per rank, one halo image at each boundary, NO collective.
+* bundle adjustment: points (with all their observations) are partitioned over ranks, cameras + intrinsics are
+  replicated; per LM iteration ONE sum all-reduce of the reduced-camera-system message and one of 4 step scalars.
+  The library calls back into `make_allreduce_hook`'s function, which runs torch.distributed.all_reduce (RCCL over
+  xGMI with the nccl backend; gloo in the CPU tests) on a zero-copy view of the library's buffer.
+"""
+import os
+
+import numpy as np
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend=None):
+    """torch.distributed over RANK/WORLD_SIZE/MASTER_* (nccl == RCCL on ROCm when a GPU is present, else gloo)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n, rank, world):
+    """Contiguous block [lo, hi) of n units for this rank (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_pairs(n_img, rank, world):
+    """Chain pairs (i, i+1) of match_features_for_all for this rank, the images it must hold, and the pair list
+    re-indexed into that local image list."""
+    lo, hi = shard_range(max(n_img - 1, 0), rank, world)
+    images = list(range(lo, hi + 1)) if hi > lo else []
+    pairs_global = np.stack([np.arange(lo, hi), np.arange(lo + 1, hi + 1)], 1).astype(np.int32) if hi > lo else np.zeros((0, 2), np.int32)
+    pairs_local = pairs_global - lo
+    return pairs_global, images, pairs_local
+
+
+def shard_points(obs_cam, obs_pt, obs_uv, pts, rank, world):
+    """Partition points into contiguous id ranges with (nearly) equal observation counts; returns this rank's
+    (pts_local, obs_cam_local, obs_pt_local (re-indexed), obs_uv_local, point_ids)."""
+    obs_pt = np.asarray(obs_pt); n_pt = len(pts)
+    cnt = np.bincount(obs_pt, minlength=n_pt)
+    cum = np.concatenate([[0], np.cumsum(cnt)])
+    total = cum[-1]
+    bounds = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world)] + [n_pt]
+    bounds[0] = 0
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sel = (obs_pt >= lo) & (obs_pt < hi)
+    ids = np.arange(lo, hi)
+    return (np.ascontiguousarray(pts[lo:hi]), np.ascontiguousarray(np.asarray(obs_cam)[sel]),
+            np.ascontiguousarray(obs_pt[sel] - lo).astype(np.int32), np.ascontiguousarray(np.asarray(obs_uv)[sel]), ids)
+
+
+class _CudaView:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def make_allreduce_hook(group=None, device="cuda"):
+    """fn(ptr, count, stream) -> 0: in-place sum of `count` float64 at address `ptr` over the process group.
+    device="cuda": ptr is a device pointer; the collective is enqueued on torch's current stream, which must be the
+    stream the sfmhip context uses (Context(use_torch_stream=True)).  device="cpu": ptr is a host address (tests)."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+    cache = {}
+
+    def hook(ptr, count, stream):
+        key = (ptr, count)
+        t = cache.get(key)
+        if t is None:
+            if device == "cpu":
+                buf = (ctypes.c_double * count).from_address(ptr)
+                t = torch.from_numpy(np.frombuffer(buf, np.float64, count))
+            else:
+                t = torch.as_tensor(_CudaView(ptr, count), device="cuda")
+            cache[key] = t
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return 0
+
+    return hook

@@ -16,6 +16,6 @@ def pytest_configure(config):
 def ctx():
     """One libsfmhip context for the whole GPU session (fails loudly without a GPU)."""
     from sfm_opencv_amd.api import Context
-    c = Context(0)
+    c = Context(0, use_torch_stream=True)   # torch allocations, copies and the library share one stream
     yield c
     c.close()
