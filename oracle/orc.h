@@ -77,7 +77,8 @@ int  orc_ba_solve(double* K4, double* ext6, int n_cam, double* pts, int n_pt,
                   int trace_cap);
 /* One linearisation at the given parameters (jacobi scaling computed at these parameters):
  * reduced camera system S (n x n row-major, full symmetric), rhs (n), cost.
- * n = 6*(n_cam - fix_first) + 4*(!fix_intrinsics).  Returns n.  S/rhs may be NULL to query n. */
+ * n = 6*(n_cam - fix_first) + 4*(!fix_intrinsics).  Returns n.  S/rhs may be NULL to query n.
+ * radius < 0: points damped with |radius|, camera-side damping skipped (the form that adds up over point shards). */
 int  orc_ba_reduced_system(const double* K4, const double* ext6, int n_cam, const double* pts, int n_pt,
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
                            const orc_ba_options* opts, double radius, double* S, double* rhs, double* cost);

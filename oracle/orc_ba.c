@@ -284,6 +284,7 @@ static int inv3_spd(const double V[9], double Vi[9])
 
 /* Build the reduced system for damping D2 (per free parameter, [n | 3 np]); S full symmetric n x n.
  * Also returns per-point Vinv (9 np) and b (3 np) for the back-substitution. */
+static int g_skip_cam_damping = 0;   /* orc_ba_reduced_system with radius < 0: additive-over-shards form */
 static int build_reduced(const prob* P, const double* r, const double* J, const double* D2,
                          double* S, double* rhs, double* Vinv_all, double* b_all)
 {
@@ -377,7 +378,7 @@ static int build_reduced(const prob* P, const double* r, const double* J, const 
             for (int j = 0; j < n; ++j) S[(size_t)i * n + j] += St[(size_t)i * n + j];
         for (int i = 0; i < n; ++i) rhs[i] += St[(size_t)n * n + i];
     }
-    for (int i = 0; i < n; ++i) S[(size_t)i * n + i] += D2[i];
+    if (!g_skip_cam_damping) for (int i = 0; i < n; ++i) S[(size_t)i * n + i] += D2[i];
     free(Sbuf);
     return fail ? -1 : 0;
 }
@@ -634,8 +635,10 @@ int orc_ba_reduced_system(const double* K4, const double* ext, int nc, const dou
     double c = evaluate(&P, K4, ext, pts, r, J);
     if (cost) *cost = c;
     col_sqnorm(&P, J, diag);
-    for (size_t i = 0; i < m; ++i) diag[i] = fmin(fmax(diag[i], o.min_lm_diagonal), o.max_lm_diagonal) / radius;
+    for (size_t i = 0; i < m; ++i) diag[i] = fmin(fmax(diag[i], o.min_lm_diagonal), o.max_lm_diagonal) / fabs(radius);
+    g_skip_cam_damping = radius < 0.0;
     int rc = build_reduced(&P, r, J, diag, S, rhs, Vinv, bp);
+    g_skip_cam_damping = 0;
     free(r); free(J); free(Vinv); free(bp); free(diag);
     prob_free(&P);
     return rc ? -1 : n;
