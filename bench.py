@@ -108,8 +108,7 @@ def main():
     def match_pass():
         if n_pairs_l == 0:
             return
-        for s in sets:
-            s.refresh()
+        ctx.refresh_descsets(sets)
         ctx.match_pairs_dev(sets, pairs_l, d_matches, n_desc, d_counts)
         h_matches.copy_(d_matches, non_blocking=True)
         h_counts.copy_(d_counts, non_blocking=True)

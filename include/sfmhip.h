@@ -77,6 +77,8 @@ int sfmhip_descset_create_hamming2_dev (sfmhip_ctx*, const uint8_t* d_desc, int 
 void sfmhip_descset_destroy(sfmhip_descset*);
 /* re-run the device preparation pass (int8 copy + norms) on the set's float rows; enqueues only */
 int sfmhip_descset_refresh(sfmhip_descset*);
+/* the same for n sets in ONE launch (what a new batch of frames costs before its pairs are matched) */
+int sfmhip_descsets_refresh(sfmhip_ctx*, sfmhip_descset* const* sets, int n);
 /* kind = SFMHIP_DESC_*; exact_u8 = 1 when the int8 MFMA path is usable (synchronises) */
 int sfmhip_descset_info(sfmhip_descset*, int* kind, int* rows, int* dim, int* exact_u8);
 

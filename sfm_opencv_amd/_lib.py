@@ -45,7 +45,7 @@ SYMBOLS = [
     "sfmhip_version",
     "sfmhip_descset_create_l2_host", "sfmhip_descset_create_l2_dev",
     "sfmhip_descset_create_hamming2_host", "sfmhip_descset_create_hamming2_dev",
-    "sfmhip_descset_destroy", "sfmhip_descset_refresh", "sfmhip_descset_info",
+    "sfmhip_descset_destroy", "sfmhip_descset_refresh", "sfmhip_descsets_refresh", "sfmhip_descset_info",
     "sfmhip_knn2_dev", "sfmhip_knn2_l2_f32", "sfmhip_knn2_hamming2_u8", "sfmhip_ratio_filter",
     "sfmhip_match_features_l2", "sfmhip_match_features_hamming2",
     "sfmhip_match_pairs_dev", "sfmhip_match_pairs", "sfmhip_l2_distance_matrix_dev",
@@ -88,6 +88,7 @@ def load():
         "sfmhip_descset_create_hamming2_dev": (i32, [vp, vp, i32, i32, sz, C.POINTER(vp)]),
         "sfmhip_descset_destroy": (None, [vp]),
         "sfmhip_descset_refresh": (i32, [vp]),
+        "sfmhip_descsets_refresh": (i32, [vp, C.POINTER(vp), i32]),
         "sfmhip_descset_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "sfmhip_knn2_dev": (i32, [vp, vp, vp, vp, vp, i32]),
         "sfmhip_knn2_l2_f32": (i32, [vp, vp, i32, vp, i32, i32, sz, sz, vp, vp]),

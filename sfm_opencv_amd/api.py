@@ -115,6 +115,11 @@ class Context:
         self._check(self.lib.sfmhip_descset_create_hamming2_dev(self.h, desc.data_ptr(), rows, nb, desc.stride(0), C.byref(out)))
         return DescSet(self, out, rows, keepalive=desc)
 
+    def refresh_descsets(self, sets):
+        """re-run the preparation pass of many sets in one launch (enqueues only)"""
+        arr = (C.c_void_p * len(sets))(*[s.handle for s in sets])
+        self._check(self.lib.sfmhip_descsets_refresh(self.h, arr, len(sets)))
+
     def knn2_dev(self, qset, tset, idx2, dist2, force_path=0):
         """idx2 (nq,2) int32 / dist2 (nq,2) float32 torch CUDA tensors; enqueues only."""
         self._check(self.lib.sfmhip_knn2_dev(self.h, qset.handle, tset.handle, idx2.data_ptr(), dist2.data_ptr(), force_path))

@@ -23,6 +23,7 @@
 
 typedef int   v4i  __attribute__((ext_vector_type(4)));
 typedef int   v16i __attribute__((ext_vector_type(16)));
+typedef float v4f  __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // descriptor preparation
@@ -55,6 +56,37 @@ __global__ void prep_l2_kernel(const float* __restrict__ src, size_t ld, int row
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) norm[row] = acc;
     if (bad) atomicOr(flag, 1);
+}
+
+// batched form: one launch prepares many images (blockIdx.y = image)
+struct PrepDesc { const float* src; size_t ld; int rows, dim, dim_pad, rows_pad; int8_t* dst; int32_t* norm; int* flag; };
+__global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl)
+{
+    const PrepDesc d = tbl[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= d.rows_pad) return;
+    if (row >= d.rows) {
+        for (int k = lane; k < d.dim_pad; k += 64) d.dst[(size_t)row * d.dim_pad + k] = 0;
+        if (lane == 0) d.norm[row] = PAD_NORM;
+        return;
+    }
+    int acc = 0, bad = 0;
+    for (int k = lane; k < d.dim_pad; k += 64) {
+        int8_t o = 0;
+        if (k < d.dim) {
+            const float v = d.src[(size_t)row * d.ld + k];
+            const float r = rintf(v);
+            if (!(v >= 0.0f && v <= 255.0f) || r != v) bad = 1;
+            const int q = (int)fminf(fmaxf(r, 0.0f), 255.0f) - 128;
+            o = (int8_t)q;
+            acc += q * q;
+        }
+        d.dst[(size_t)row * d.dim_pad + k] = o;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) d.norm[row] = acc;
+    if (bad) atomicOr(d.flag, 1);
 }
 
 // Hamming: copy rows into 64-byte zero-padded rows (16 dwords)
@@ -218,12 +250,13 @@ template <int KS>
 __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
                                                          const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
                                                          int nq, int nt, int nt_pad, int blocks_per_wg,
-                                                         float* __restrict__ dist, size_t ldd, int vec_ok)
+                                                         float* __restrict__ dist, size_t ldd, int vec_ok, int exp_mode)
 {
     constexpr int DP = 32 * KS;
     constexpr int CH = DP / 16;
     constexpr int PASSES = (128 * CH) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4 + 4 * 32 * 36 * 4];
+    float* stage_out = (float*)(lds + 2 * 128 * DP + 2 * 128 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -263,6 +296,8 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     for (int blk = 0; blk < nblocks; ++blk) {
         const int buf = blk & 1;
         if (blk + 1 < nblocks) g_load(blk + 1);
+        // all four 32-train tiles of the block first: four independent MFMA chains in flight, then four epilogues
+        v16i accs[4];
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int r = tile * 32 + l31;
@@ -273,21 +308,41 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
                 const v4i a = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qfrag[ks], acc, 0, 0, 0);
             }
-            // C[row = train (reg), col = query (lane&31)]: regs 4g..4g+3 <-> trains 8g + 4 half + {0,1,2,3}
+            accs[tile] = acc;
+        }
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const v16i acc = accs[tile];
+            // C[row = train (reg), col = query (lane&31)]: regs 4g..4g+3 <-> trains 8g + 4 half + {0,1,2,3}.
+            // The tile goes through a per-wave LDS slab [32 queries][36 floats] so that every global store instruction
+            // writes 8 query rows x 128 contiguous bytes (full cache lines) instead of 32 scattered 32-byte pieces.
+            float* slab = stage_out + wave * (32 * 36);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int tl = tile * 32 + 8 * g + 4 * half;
                 const v4i tn = *(const v4i*)(lds_norm + buf * 128 + tl);
-                const int tg = t_begin + blk * 128 + tl;
                 float4 o;
+                if (exp_mode & 1) {
+                    o.x = (float)(qn + tn.x - 2 * acc[4 * g + 0]); o.y = (float)(qn + tn.y - 2 * acc[4 * g + 1]);
+                    o.z = (float)(qn + tn.z - 2 * acc[4 * g + 2]); o.w = (float)(qn + tn.w - 2 * acc[4 * g + 3]);
+                } else {
                 o.x = sqrtf((float)(qn + tn.x - 2 * acc[4 * g + 0]));
                 o.y = sqrtf((float)(qn + tn.y - 2 * acc[4 * g + 1]));
                 o.z = sqrtf((float)(qn + tn.z - 2 * acc[4 * g + 2]));
                 o.w = sqrtf((float)(qn + tn.w - 2 * acc[4 * g + 3]));
-                if (qrow < nq) {
-                    float* dst = dist + (size_t)qrow * ldd + tg;
+                }
+                *(float4*)(slab + l31 * 36 + 8 * g + 4 * half) = o;
+            }
+            const int tg0 = t_begin + blk * 128 + tile * 32;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 4;
+                const float4 o = *(const float4*)(slab + row * 36 + col);
+                const int qr = q0 + row, tg = tg0 + col;
+                if (qr < nq && !((exp_mode & 2) && o.x != -12345.0f)) {
+                    float* dst = dist + (size_t)qr * ldd + tg;
                     if (vec_ok && tg + 3 < nt) {
-                        *(float4*)dst = o;
+                        { v4f ov = { o.x, o.y, o.z, o.w }; __builtin_nontemporal_store(ov, (v4f*)dst); }      // streamed once: keep it out of the way of the L2-resident inputs
                     } else {
                         if (tg + 0 < nt) dst[0] = o.x;
                         if (tg + 1 < nt) dst[1] = o.y;
@@ -319,99 +374,96 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
     const PairDesc pd = pairs[blockIdx.z];
     const int dim = pd.dim, chunk = blockIdx.y;
     if (chunk >= pd.nchunks) return;
-    int rows[QR];
-    if (row_list) {
-        const int cnt = row_count[blockIdx.z];
-        if ((int)blockIdx.x * QR >= cnt) return;
-#pragma unroll
-        for (int r = 0; r < QR; ++r) {
-            const int k = blockIdx.x * QR + r;
-            rows[r] = k < cnt ? row_list[pd.list_off + k] : -1;
-        }
-    } else {
-        if ((int)blockIdx.x * QR >= pd.nq) return;
-#pragma unroll
-        for (int r = 0; r < QR; ++r) { const int k = blockIdx.x * QR + r; rows[r] = k < pd.nq ? k : -1; }
-    }
+    const int total = row_list ? row_count[blockIdx.z] : pd.nq;
     const int tid = threadIdx.x;
-    for (int r = 0; r < QR; ++r) {
-        const int row = rows[r] < 0 ? 0 : rows[r];
-        for (int k = tid; k < dim; k += 256) sm_q[r * dim + k] = pd.qf[(size_t)row * pd.ldq + k];
-    }
-    __syncthreads();
     const int t_begin = chunk * pd.chunk_rows;
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt) t_end = pd.nt;
+    // groups of QR rows, strided over the grid (the re-score launch uses a small grid: its list is normally empty)
+    for (int grp = blockIdx.x; grp * QR < total; grp += gridDim.x) {
+        int rows[QR];
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            const int k = grp * QR + r;
+            rows[r] = k < total ? (row_list ? row_list[pd.list_off + k] : k) : -1;
+        }
+        __syncthreads();
+        for (int r = 0; r < QR; ++r) {
+            const int row = rows[r] < 0 ? 0 : rows[r];
+            for (int k = tid; k < dim; k += 256) sm_q[r * dim + k] = pd.qf[(size_t)row * pd.ldq + k];
+        }
+        __syncthreads();
 
-    long long k1[QR], k2[QR];
+        long long k1[QR], k2[QR];
 #pragma unroll
-    for (int r = 0; r < QR; ++r) { k1[r] = KEY_INVALID; k2[r] = KEY_INVALID; }
+        for (int r = 0; r < QR; ++r) { k1[r] = KEY_INVALID; k2[r] = KEY_INVALID; }
 
-    for (int j = t_begin + tid; j < t_end; j += 256) {
-        const float* b = pd.tf + (size_t)j * pd.ldt;
-        float acc[QR][16];
-#pragma unroll
-        for (int r = 0; r < QR; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
-        int k = 0;
-        for (; k <= dim - 16; k += 16) {
-            float bb[16];
-            if (ALIGNED) {
-                const float4 b0 = *(const float4*)(b + k), b1 = *(const float4*)(b + k + 4);
-                const float4 b2 = *(const float4*)(b + k + 8), b3 = *(const float4*)(b + k + 12);
-                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-                bb[8] = b2.x; bb[9] = b2.y; bb[10] = b2.z; bb[11] = b2.w; bb[12] = b3.x; bb[13] = b3.y; bb[14] = b3.z; bb[15] = b3.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) bb[i] = b[k + i];
-            }
+        for (int j = t_begin + tid; j < t_end; j += 256) {
+            const float* b = pd.tf + (size_t)j * pd.ldt;
+            float acc[QR][16];
 #pragma unroll
             for (int r = 0; r < QR; ++r)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float t = sm_q[r * dim + k + i] - bb[i];
-                    const float m = t * t;
-                    acc[r][i] = m + acc[r][i];
+                for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+            int k = 0;
+            for (; k <= dim - 16; k += 16) {
+                float bb[16];
+                if (ALIGNED) {
+                    const float4 b0 = *(const float4*)(b + k), b1 = *(const float4*)(b + k + 4);
+                    const float4 b2 = *(const float4*)(b + k + 8), b3 = *(const float4*)(b + k + 12);
+                    bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+                    bb[8] = b2.x; bb[9] = b2.y; bb[10] = b2.z; bb[11] = b2.w; bb[12] = b3.x; bb[13] = b3.y; bb[14] = b3.z; bb[15] = b3.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) bb[i] = b[k + i];
                 }
+#pragma unroll
+                for (int r = 0; r < QR; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float t = sm_q[r * dim + k + i] - bb[i];
+                        const float m = t * t;
+                        acc[r][i] = m + acc[r][i];
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < QR; ++r) {
+                float s[4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    s[l] = ((acc[r][l] + acc[r][4 + l]) + acc[r][8 + l]) + acc[r][12 + l];
+                float d = (s[0] + s[2]) + (s[1] + s[3]);
+                for (int kk = k; kk < dim; ++kk) {
+                    const float t = sm_q[r * dim + kk] - b[kk];
+                    const float m = t * t;
+                    d = d + m;
+                }
+                const float dist = sqrtf(d);
+                if (STORE_ALL) {
+                    if (rows[r] >= 0) dist_out[(size_t)rows[r] * ldd + j] = dist;
+                } else {
+                    const long long key = ((long long)__float_as_int(dist) << 32) | (unsigned int)j;
+                    if (key < k2[r]) { if (key < k1[r]) { k2[r] = k1[r]; k1[r] = key; } else k2[r] = key; }
+                }
+            }
         }
+        if (STORE_ALL) continue;
+        const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int r = 0; r < QR; ++r) {
-            float s[4];
 #pragma unroll
-            for (int l = 0; l < 4; ++l)
-                s[l] = ((acc[r][l] + acc[r][4 + l]) + acc[r][8 + l]) + acc[r][12 + l];
-            float d = (s[0] + s[2]) + (s[1] + s[3]);
-            for (int kk = k; kk < dim; ++kk) {
-                const float t = sm_q[r * dim + kk] - b[kk];
-                const float m = t * t;
-                d = d + m;
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long o1 = shfl_xor_ll(k1[r], off), o2 = shfl_xor_ll(k2[r], off);
+                merge2(k1[r], k2[r], o1, o2);
             }
-            const float dist = sqrtf(d);
-            if (STORE_ALL) {
-                if (rows[r] >= 0) dist_out[(size_t)rows[r] * ldd + j] = dist;
-            } else {
-                const long long key = ((long long)__float_as_int(dist) << 32) | (unsigned int)j;
-                if (key < k2[r]) { if (key < k1[r]) { k2[r] = k1[r]; k1[r] = key; } else k2[r] = key; }
-            }
+            if (lane == 0) { red[wave][r][0] = k1[r]; red[wave][r][1] = k2[r]; }
         }
-    }
-    if (STORE_ALL) return;
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int r = 0; r < QR; ++r) {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long o1 = shfl_xor_ll(k1[r], off), o2 = shfl_xor_ll(k2[r], off);
-            merge2(k1[r], k2[r], o1, o2);
+        __syncthreads();
+        if (tid < QR && rows[tid] >= 0) {
+            long long a1 = red[0][tid][0], a2 = red[0][tid][1];
+            for (int w = 1; w < 4; ++w) merge2(a1, a2, red[w][tid][0], red[w][tid][1]);
+            long long* o = part + 2 * (pd.part_off + (long long)rows[tid] * pd.nchunks + chunk);
+            o[0] = a1; o[1] = a2;
         }
-        if (lane == 0) { red[wave][r][0] = k1[r]; red[wave][r][1] = k2[r]; }
-    }
-    __syncthreads();
-    if (tid < QR && rows[tid] >= 0) {
-        long long a1 = red[0][tid][0], a2 = red[0][tid][1];
-        for (int w = 1; w < 4; ++w) merge2(a1, a2, red[w][tid][0], red[w][tid][1]);
-        long long* o = part + 2 * (pd.part_off + (long long)rows[tid] * pd.nchunks + chunk);
-        o[0] = a1; o[1] = a2;
     }
 }
 
@@ -691,6 +743,30 @@ int sfmhip_descset_refresh(sfmhip_descset* s)
     return SFMHIP_OK;
 }
 
+// one launch for many images: what a per-frame "descriptors arrived" step costs when the float rows were rewritten
+int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
+{
+    SFM_ARG_CHECK(ctx, ctx && (sets || n == 0) && n >= 0);
+    std::vector<PrepDesc> tbl;
+    int max_pad = 0;
+    for (int i = 0; i < n; ++i) {
+        const sfmhip_descset* s = sets[i];
+        SFM_ARG_CHECK(ctx, s != nullptr);
+        if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) continue;
+        PrepDesc d; d.src = s->d_f32; d.ld = s->ld; d.rows = s->rows; d.dim = s->dim; d.dim_pad = s->dim_pad; d.rows_pad = s->rows_pad;
+        d.dst = s->d_i8; d.norm = s->d_norm; d.flag = s->d_flag;
+        tbl.push_back(d);
+        if (s->rows_pad > max_pad) max_pad = s->rows_pad;
+    }
+    if (tbl.empty()) return SFMHIP_OK;
+    void* d_tbl = nullptr;
+    int rc = sfm_scratch2(ctx, tbl.size() * sizeof(PrepDesc), &d_tbl); if (rc) return rc;
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(prep_l2_batched_kernel, dim3(ceil_div(max_pad, 4), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepDesc*)d_tbl);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
 int sfmhip_descset_info(sfmhip_descset* s, int* kind, int* rows, int* dim, int* exact_u8)
 {
     if (!s) return SFMHIP_E_ARG;
@@ -796,7 +872,9 @@ template <bool ALIGNED>
 static void launch_exact(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& W, int n_pairs, bool use_list)
 {
     constexpr int QR = 4;
-    const dim3 grid(ceil_div(P.max_nq > 0 ? P.max_nq : 1, QR), P.max_chunks, n_pairs);
+    int gx = ceil_div(P.max_nq > 0 ? P.max_nq : 1, QR);
+    if (use_list && gx > 8) gx = 8;          // the re-score list is normally empty: a few blocks per (chunk, pair) loop over it
+    const dim3 grid(gx, P.max_chunks, n_pairs);
     const size_t shm = (size_t)QR * P.dim * sizeof(float);
     hipLaunchKernelGGL((knn2_exact_f32_kernel<QR, ALIGNED, false>), grid, dim3(256), shm, ctx->stream,
                        W.d_pd, W.d_part, use_list ? W.d_list : (const int*)nullptr, W.d_count, (float*)nullptr, (size_t)0);
@@ -980,12 +1058,14 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
     const bool exact = query->exact_u8 && train->exact_u8;
     SFM_ARG_CHECK(ctx, !(force_path == 2 && !exact));
     if (exact && force_path != 1) {
-        const int bpw = 4;   // 4 x 128 trains per workgroup
+        const char* em = getenv("SFMHIP_EXP_DISTMAT"); const int exp_mode = em ? atoi(em) : 0;   // timing experiments only
+        const char* eb = getenv("SFMHIP_EXP_BPW");
+        const int bpw = eb ? atoi(eb) : 4;   // 4 x 128 trains per workgroup
         const dim3 grid(query->rows_pad / 128, ceil_div(train->rows_pad / 128, bpw));
         const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
         const int ks = query->dim_pad / 32;
 #define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
-                                        train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok)
+                                        train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok, exp_mode)
         if (ks == 1) DM_LAUNCH(1); else if (ks == 2) DM_LAUNCH(2); else DM_LAUNCH(4);
 #undef DM_LAUNCH
         SFM_HIP_TRY(ctx, hipGetLastError());
