@@ -156,6 +156,11 @@ struct sfmhip_ba {
     int *d_blk_cam = nullptr, *d_blk_start = nullptr, *d_items = nullptr;
     int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
     std::vector<int> host_blk_cam;
+    // layout of the reduced system (nested-dissection ordering of the camera chain, segments padded to 32-blocks)
+    int npad_max = 0, nseg = 1, top_blk = 0;
+    std::vector<int> cam_pos, pos_param;      // camera -> first position (-1 constant); position -> natural index (-1 pad)
+    int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
+    double* d_topbuf = nullptr; size_t topbuf_count = 0;
     double* d_ouv = nullptr;
     // work
     double *d_scale_c = nullptr, *d_scale_p = nullptr, *d_Vinv = nullptr, *d_bp = nullptr, *d_WK = nullptr, *d_colsq_p = nullptr;
@@ -201,6 +206,7 @@ static BADev make_dev(const sfmhip_ba* h, double radius)
     P.K = h->d_K; P.ext = h->d_ext; P.pts = h->d_pts; P.Kc = h->d_Kc; P.extc = h->d_extc; P.ptsc = h->d_ptsc;
     P.pt_start = h->d_pt_start; P.ocam = h->d_ocam; P.ouv = h->d_ouv;
     P.cam_start = h->d_cam_start; P.cam_obs = h->d_cam_obs; P.opt = h->d_opt;
+    P.cam_pos = h->d_cam_pos; P.posmask = h->d_posmask;
     P.scale_c = h->d_scale_c; P.scale_p = h->d_scale_p;
     P.Vinv = h->d_Vinv; P.bp = h->d_bp; P.WK = h->d_WK; P.colsq_p = h->d_colsq_p;
     const size_t np2 = (size_t)h->npad * h->npad;
@@ -246,7 +252,33 @@ static int enqueue_solve(sfmhip_ba* h)
     const int nb = h->nbk, ld = h->npad;
     if (h->use_sparse) {
         double* rhs_rw = h->d_msg + (size_t)h->npad * h->npad;
-        hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, nb, h->d_prow_start, h->d_prow, rhs_rw, h->d_y, h->d_err);
+        SolverPlan pl; pl.prow_start = h->d_prow_start; pl.prow = h->d_prow; pl.nb = nb; pl.top_blk = h->top_blk;
+        { const char* e = getenv("SFMHIP_EXP_SOLVER"); pl.dbg = e ? atoi(e) : 0; }
+        static long long* d_stamps = nullptr; static int stamp_calls = 0;
+        pl.stamps = nullptr;
+        if (getenv("SFMHIP_SOLVER_STAMPS")) {
+            if (!d_stamps) { (void)hipMalloc((void**)&d_stamps, 8 * 512 * sizeof(long long)); (void)hipMemset(d_stamps, 0, 8 * 512 * sizeof(long long)); }
+            pl.stamps = d_stamps;
+            if (++stamp_calls == 8) {          // dump once, after a few warm iterations
+                (void)hipStreamSynchronize(st);
+                std::vector<long long> hs(8 * (size_t)nb);
+                (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                for (int k = 0; k < nb; ++k) {
+                    fprintf(stderr, "[stamps] panel %3d:", k);
+                    for (int i = 1; i <= 6; ++i) fprintf(stderr, " %7lld", hs[8 * k + i] - hs[8 * k + i - 1]);
+                    fprintf(stderr, "   (load+sync | prefetch..chol | sync | trsm+sync | trailing | rhs+sync) x10ns\n");
+                }
+            }
+        }
+        if (h->nseg <= 1) {
+            pl.top_blk = nb;
+            hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, rhs_rw, h->d_y, h->d_err);
+        } else {
+            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
+            hipLaunchKernelGGL(chol_nd_forward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_topbuf, h->d_err);
+            hipLaunchKernelGGL(chol_nd_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->nseg, rhs_rw, h->d_topbuf, h->d_y, h->d_err);
+            hipLaunchKernelGGL(chol_nd_backward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_y);
+        }
         SFM_HIP_TRY(ctx, hipGetLastError());
         return SFMHIP_OK;
     }
@@ -276,56 +308,125 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     return call_allreduce(h, h->d_back4, 4);
 }
 
-// Block fill pattern of the reduced system (32x32 blocks) -> per-panel row lists for chol_sparse_kernel.
-// Multi-rank: the pattern is the union over ranks (S is summed), taken through the all-reduce hook.
+// Layout + block fill pattern of the reduced system -> per-panel row lists for the solver kernels.
+//  1. camera adjacency (cameras sharing a point); multi-rank: union over ranks through the all-reduce hook.
+//  2. ordering: if the camera graph is a narrow band (the reference's tracks only chain through consecutive frames),
+//     cut the chain into `nseg` segments separated by `w` cameras; order [segment interiors (each padded to whole
+//     32-blocks) | separators | intrinsics].  Segment interiors are mutually independent => one workgroup each.
+//  3. symbolic block factorisation in that order -> rows(k); verify the independence, else fall back to one segment.
 static int build_solver_plan(sfmhip_ba* h)
 {
     sfmhip_ctx* ctx = h->ctx;
-    const int nb = h->nbk;
-    std::vector<double> pat((size_t)nb * nb, 0.0);
-    auto mark = [&](int lo_a, int hi_a, int lo_b, int hi_b) {       // scalar index ranges [lo, hi)
-        for (int i = lo_a / NB; i <= (hi_a - 1) / NB; ++i)
-            for (int j = lo_b / NB; j <= (hi_b - 1) / NB; ++j) { pat[(size_t)i * nb + j] = 1.0; pat[(size_t)j * nb + i] = 1.0; }
-    };
-    for (int i = 0; i < nb; ++i) pat[(size_t)i * nb + i] = 1.0;
-    for (int c = h->fix0; c < h->nc; ++c) {
-        const int co = 6 * (c - h->fix0);
-        mark(co, co + 6, co, co + 6);
-        if (!h->fixK) mark(co, co + 6, h->koff, h->koff + 4);
-    }
-    if (!h->fixK) mark(h->koff, h->koff + 4, h->koff, h->koff + 4);
+    const int nc = h->nc, ncf = h->ncf, f0 = h->fix0;
+    // ---- 1. adjacency among free cameras (index i = c - fix0)
+    std::vector<double> adj((size_t)ncf * ncf, 0.0);
     for (size_t b = 0; b + 1 < h->host_blk_cam.size(); b += 2) {
-        const int oa = 6 * (h->host_blk_cam[b] - h->fix0), ob = 6 * (h->host_blk_cam[b + 1] - h->fix0);
-        mark(oa, oa + 6, ob, ob + 6);
+        const int a = h->host_blk_cam[b] - f0, c = h->host_blk_cam[b + 1] - f0;
+        adj[(size_t)a * ncf + c] = 1.0; adj[(size_t)c * ncf + a] = 1.0;
     }
-    if (h->ar_fn) {
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_msg, pat.data(), pat.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        int rc = call_allreduce(h, h->d_msg, pat.size()); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(pat.data(), h->d_msg, pat.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (h->ar_fn && ncf > 0) {
+        if (adj.size() > h->msg_count) { ctx->last_error = "adjacency larger than the message buffer"; return SFMHIP_E_ARG; }
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_msg, adj.data(), adj.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int rc = call_allreduce(h, h->d_msg, adj.size()); if (rc) return rc;
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(adj.data(), h->d_msg, adj.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<char> P((size_t)nb * nb, 0);
-    for (int i = 0; i < nb; ++i) for (int j = 0; j <= i; ++j) P[(size_t)i * nb + j] = pat[(size_t)i * nb + j] != 0.0;
-    std::vector<int> start(nb + 1, 0), rows;
-    int maxR = 0;
-    for (int k = 0; k < nb; ++k) {
-        std::vector<int> rk;
-        for (int i = k + 1; i < nb; ++i) if (P[(size_t)i * nb + k]) rk.push_back(i);
-        for (size_t a = 0; a < rk.size(); ++a) for (size_t b = 0; b <= a; ++b) P[(size_t)rk[a] * nb + rk[b]] = 1;
-        maxR = std::max(maxR, (int)rk.size());
-        rows.insert(rows.end(), rk.begin(), rk.end());
-        start[k + 1] = (int)rows.size();
-    }
-    h->max_panel_rows = maxR;
-    h->use_sparse = maxR <= SRMAX && h->npad <= (SRMAX * SNB + 1) * SLD;
-    if (getenv("SFMHIP_DENSE_SOLVER")) h->use_sparse = false;
-    if (h->use_sparse) {
-        if (!h->d_prow_start) { int rc = dalloc(h, &h->d_prow_start, (size_t)nb + 1); if (rc) return rc; rc = dalloc(h, &h->d_prow, (size_t)nb * SRMAX + 1); if (rc) return rc; }
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        if (!rows.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    int w = 0;
+    for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c) if (adj[(size_t)a * ncf + c] != 0.0) w = std::max(w, a - c);
+
+    int want = 4;
+    if (const char* e = getenv("SFMHIP_ND_SEGMENTS")) want = std::max(1, atoi(e));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // ---- 2. ordering
+        int P = attempt == 0 ? want : 1;
+        while (P > 1 && (w < 1 || (ncf - (P - 1) * w) / P < 3 * w + 6)) P /= 2;
+        if (P < 1) P = 1;
+        std::vector<int> is_sep((size_t)std::max(ncf, 1), 0), seg_of((size_t)std::max(ncf, 1), 0);
+        if (P > 1) {
+            const int interior = ncf - (P - 1) * w;
+            int pos = 0;
+            for (int sgi = 0; sgi < P; ++sgi) {
+                const int len = interior / P + (sgi < interior % P ? 1 : 0);
+                for (int k = 0; k < len; ++k) seg_of[pos++] = sgi;
+                if (sgi + 1 < P) for (int k = 0; k < w; ++k) { is_sep[pos] = 1; seg_of[pos++] = sgi; }
+            }
+        }
+        h->cam_pos.assign((size_t)nc, -1);
+        std::vector<int> seg_blk(P + 1, 0);
+        int pos = 0;
+        for (int sgi = 0; sgi < P; ++sgi) {
+            seg_blk[sgi] = pos / NB;
+            for (int i = 0; i < ncf; ++i) if (!is_sep[i] && seg_of[i] == sgi) { h->cam_pos[i + f0] = pos; pos += 6; }
+            if (P > 1) pos = round_up(pos, NB);
+        }
+        seg_blk[P] = pos / NB;
+        const int top_start = pos;
+        for (int i = 0; i < ncf; ++i) if (is_sep[i]) { h->cam_pos[i + f0] = pos; pos += 6; }
+        h->koff = pos;
+        if (!h->fixK) pos += 4;
+        const int npad = std::max(NB, round_up(pos, NB));
+        if (npad > h->npad_max) { if (P == 1) { ctx->last_error = "internal: npad_max"; return SFMHIP_E_ARG; } continue; }
+        const int nb = npad / NB;
+        h->npad = npad; h->nbk = nb; h->nseg = P; h->top_blk = P > 1 ? top_start / NB : nb;
+        h->pos_param.assign((size_t)npad, -1);
+        for (int c = f0; c < nc; ++c) for (int j = 0; j < 6; ++j) h->pos_param[h->cam_pos[c] + j] = 6 * (c - f0) + j;
+        if (!h->fixK) for (int j = 0; j < 4; ++j) h->pos_param[h->koff + j] = 6 * ncf + j;
+
+        // ---- 3. block pattern + symbolic factorisation
+        std::vector<char> Pm((size_t)nb * nb, 0);
+        auto mark = [&](int lo_a, int lo_b, int len_a, int len_b) {
+            for (int i = lo_a / NB; i <= (lo_a + len_a - 1) / NB; ++i)
+                for (int j = lo_b / NB; j <= (lo_b + len_b - 1) / NB; ++j) { const int hi = std::max(i, j), lo = std::min(i, j); Pm[(size_t)hi * nb + lo] = 1; }
+        };
+        for (int i = 0; i < nb; ++i) Pm[(size_t)i * nb + i] = 1;
+        for (int c = f0; c < nc; ++c) {
+            mark(h->cam_pos[c], h->cam_pos[c], 6, 6);
+            if (!h->fixK) mark(h->cam_pos[c], h->koff, 6, 4);
+        }
+        if (!h->fixK) mark(h->koff, h->koff, 4, 4);
+        for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c)
+            if (adj[(size_t)a * ncf + c] != 0.0) mark(h->cam_pos[a + f0], h->cam_pos[c + f0], 6, 6);
+        std::vector<int> start(nb + 1, 0), rows;
+        int maxR = 0; bool independent = true;
+        for (int k = 0; k < nb; ++k) {
+            std::vector<int> rk;
+            for (int i = k + 1; i < nb; ++i) if (Pm[(size_t)i * nb + k]) rk.push_back(i);
+            for (size_t a = 0; a < rk.size(); ++a) for (size_t b = 0; b <= a; ++b) Pm[(size_t)rk[a] * nb + rk[b]] = 1;
+            maxR = std::max(maxR, (int)rk.size());
+            if (P > 1 && k < h->top_blk) {
+                int sgi = 0; while (sgi + 1 < P && k >= seg_blk[sgi + 1]) ++sgi;
+                for (int i : rk) if (i < h->top_blk && !(i >= seg_blk[sgi] && i < seg_blk[sgi + 1])) independent = false;
+            }
+            rows.insert(rows.end(), rk.begin(), rk.end());
+            start[k + 1] = (int)rows.size();
+        }
+        if (P > 1 && (!independent || maxR > SRMAX)) continue;       // retry with a single segment
+        h->max_panel_rows = maxR;
+        h->use_sparse = maxR <= SRMAX && npad <= (SRMAX * SNB + 1) * SLD;
+        if (getenv("SFMHIP_DENSE_SOLVER")) h->use_sparse = false;
+        // ---- upload
+        std::vector<int> mask((size_t)h->npad_max, 0);
+        for (int i = 0; i < npad; ++i) mask[i] = h->pos_param[i] >= 0;
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_cam_pos, h->cam_pos.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_posmask, mask.data(), mask.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_seg_blk, seg_blk.data(), seg_blk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (h->use_sparse) {
+            SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            if (!rows.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            if (P > 1) {
+                const size_t ntop = (size_t)(nb - h->top_blk) * NB, need = (size_t)P * (ntop * ntop + ntop);
+                if (need > h->topbuf_count) {
+                    int rc = dalloc(h, &h->d_topbuf, need); if (rc) return rc;
+                    h->topbuf_count = need;
+                }
+            }
+        } else if (P > 1) continue;                                   // the dense path uses the natural single-segment layout
         SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;
+        return SFMHIP_OK;
     }
-    return SFMHIP_OK;
+    ctx->last_error = "internal: no solver layout";
+    return SFMHIP_E_ARG;
 }
 
 // iteration 0 work: jacobi scaling from the column norms at x0, |x0|
@@ -335,13 +436,13 @@ static int ba_start(sfmhip_ba* h)
     hipStream_t st = ctx->stream;
     { int rc = build_solver_plan(h); if (rc) return rc; }
     const size_t np3 = 3 * (size_t)h->np;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->npad + 255) / 256)), dim3(256), 0, st, h->d_scale_c, (size_t)h->npad, 1.0);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->npad_max + 255) / 256)), dim3(256), 0, st, h->d_scale_c, (size_t)h->npad_max, 1.0);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((np3 + 255) / 256 + 1)), dim3(256), 0, st, h->d_scale_p, np3, 1.0);
     if (h->o.jacobi_scaling) {
         int rc = enqueue_linearize(h, h->o.initial_trust_region_radius, false); if (rc) return rc;
         const double* diagU = h->d_msg + (size_t)h->npad * h->npad + h->npad;
-        hipLaunchKernelGGL(ba_scale_kernel, dim3((h->n + 255) / 256 + 1), dim3(256), 0, st, diagU, h->d_scale_c, h->n, 1);
-        hipLaunchKernelGGL(ba_scale_kernel, dim3((unsigned)((np3 + 255) / 256 + 1)), dim3(256), 0, st, h->d_colsq_p, h->d_scale_p, (int)np3, 1);
+        hipLaunchKernelGGL(ba_scale_kernel, dim3((h->npad + 255) / 256 + 1), dim3(256), 0, st, diagU, h->d_scale_c, h->npad, (const int*)h->d_posmask);
+        hipLaunchKernelGGL(ba_scale_kernel, dim3((unsigned)((np3 + 255) / 256 + 1)), dim3(256), 0, st, h->d_colsq_p, h->d_scale_p, (int)np3, (const int*)nullptr);
     }
     BADev P = make_dev(h, h->o.initial_trust_region_radius);
     const int nb = 64;
@@ -498,6 +599,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->fix0 = h->o.fix_first_camera ? 1 : 0; h->fixK = h->o.fix_intrinsics ? 1 : 0;
     h->ncf = n_cam - h->fix0; h->koff = 6 * h->ncf; h->n = 6 * h->ncf + (h->fixK ? 0 : 4);
     h->npad = std::max(NB, round_up(h->n, NB)); h->nbk = h->npad / NB;
+    h->npad_max = h->npad + NB * 8;                 // room for the per-segment padding of the nested-dissection layout
     h->n_pt_blocks = std::max(1, ceil_div(n_pt, 256));
 
     // ---- orderings (host, once per problem)
@@ -548,15 +650,17 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_cam_start, cam_start.data(), cam_start.size())); TRY_RC(dupload(h, &h->d_cam_obs, cam_obs.data(), cam_obs.size()));
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_start, blk_start.data(), blk_start.size()));
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size()));
-    TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
+    TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
+    TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_seg_blk, 16));
+    TRY_RC(dalloc(h, &h->d_prow_start, (size_t)h->npad_max / NB + 2)); TRY_RC(dalloc(h, &h->d_prow, ((size_t)h->npad_max / NB + 1) * SRMAX + 1));
     TRY_RC(dalloc(h, &h->d_Vinv, 6 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_bp, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_WK, 12 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_colsq_p, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_part_pt, 16 * (size_t)h->n_pt_blocks)); TRY_RC(dalloc(h, &h->d_part_back, 4 * (size_t)h->n_pt_blocks));
     TRY_RC(dalloc(h, &h->d_part_cam, (size_t)CAMACC * n_cam * 32));
-    TRY_RC(dalloc(h, &h->d_Linv, (size_t)h->nbk * NB * NB)); TRY_RC(dalloc(h, &h->d_y, (size_t)h->npad));
+    TRY_RC(dalloc(h, &h->d_Linv, (size_t)(h->npad_max / NB) * NB * NB)); TRY_RC(dalloc(h, &h->d_y, (size_t)h->npad_max));
     TRY_RC(dalloc(h, &h->d_back4, 4)); TRY_RC(dalloc(h, &h->d_cam2, 2)); TRY_RC(dalloc(h, &h->d_xnorm, 64)); TRY_RC(dalloc(h, &h->d_err, 1));
-    h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;   // room for <= 64 ranks
-    TRY_RC(dalloc(h, &h->d_msg, h->msg_count));
+    h->msg_count = (size_t)h->npad_max * h->npad_max + 3 * (size_t)h->npad_max + SCAL_GMAX_SLOTS + 64;   // room for <= 64 ranks
+    TRY_RC(dalloc(h, &h->d_msg, std::max(h->msg_count, (size_t)h->ncf * h->ncf)));
 #undef TRY_RC
     if (hipHostMalloc((void**)&h->h_scal, 16 * sizeof(double)) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipHostMalloc"; return SFMHIP_E_HIP; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
@@ -627,9 +731,16 @@ int sfmhip_ba_reduced_system(sfmhip_ba* h, double radius, double* S, double* rhs
     int rc = enqueue_linearize(h, std::fabs(radius), radius > 0.0); if (rc) return rc;
     SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t np2 = (size_t)h->npad * h->npad;
-    if (S && h->n) SFM_HIP_TRY(ctx, hipMemcpy2D(S, (size_t)h->n * sizeof(double), h->d_msg, (size_t)h->npad * sizeof(double),
-                                                 (size_t)h->n * sizeof(double), h->n, hipMemcpyDeviceToHost));
-    if (rhs && h->n) SFM_HIP_TRY(ctx, hipMemcpy(rhs, h->d_msg + np2, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (h->n) {
+        std::vector<double> full(np2 + h->npad);
+        SFM_HIP_TRY(ctx, hipMemcpy(full.data(), h->d_msg, full.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->npad; ++i) {
+            const int pi = h->pos_param[i];
+            if (pi < 0) continue;
+            if (rhs) rhs[pi] = full[np2 + i];
+            if (S) for (int j = 0; j < h->npad; ++j) { const int pj = h->pos_param[j]; if (pj >= 0) S[(size_t)pi * h->n + pj] = full[(size_t)i * h->npad + j]; }
+        }
+    }
     if (cost) SFM_HIP_TRY(ctx, hipMemcpy(cost, h->d_msg + np2 + 3 * (size_t)h->npad, sizeof(double), hipMemcpyDeviceToHost));
     return SFMHIP_OK;
 }

@@ -28,6 +28,9 @@ struct BADev {
     const int* pt_start; const int* ocam; const double* ouv;
     // per-camera lists (indices into the by-point ordering) and their points
     const int* cam_start; const int* cam_obs; const int* opt;
+    // layout of the reduced system: position of camera c's 6 columns (-1 = constant camera), koff = intrinsics;
+    // posmask[i] = 1 for a real parameter, 0 for a padding slot (segments are padded to whole 32-blocks)
+    const int* cam_pos; const int* posmask;
     // column scaling (cam side: npad entries; points: 3 np)
     const double* scale_c; const double* scale_p;
     // per point
@@ -46,7 +49,7 @@ struct BADev {
 #define SCAL_COST 0
 #define SCAL_GMAX_SLOTS 8     // scal[8 + rank] = local max |gradient| over this rank's points
 
-__device__ __forceinline__ int cam_off(const BADev& P, int c) { return (P.fix0 && c == 0) ? -1 : 6 * (c - P.fix0); }
+__device__ __forceinline__ int cam_off(const BADev& P, int c) { return P.cam_pos[c]; }
 
 // Corrected residual and Jacobian blocks of one observation, column-scaled; blocks of constant parameters are 0.
 struct ObsLin {
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void ba_damp_kernel(BADev P)
     __shared__ double red[4];
     double g = 0.0;
     for (int i = threadIdx.x; i < P.npad; i += 256) {
-        if (i < P.n) {
+        if (P.posmask[i]) {
             const double d = fmin(fmax(P.diagU[i], P.min_diag), P.max_diag) / P.radius;
             P.S[(size_t)i * P.npad + i] += d;
             g = fmax(g, fabs(P.graw[i] / P.scale_c[i]));
@@ -583,10 +586,10 @@ __global__ __launch_bounds__(256) void ba_damp_kernel(BADev P)
 }
 
 // jacobi scaling from the raw column norms (first linearisation, scale == 1): s = 1 / (1 + sqrt(colsq))
-__global__ void ba_scale_kernel(const double* __restrict__ colsq, double* __restrict__ scale, int n, int enabled)
+__global__ void ba_scale_kernel(const double* __restrict__ colsq, double* __restrict__ scale, int n, const int* __restrict__ mask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) scale[i] = enabled ? 1.0 / (1.0 + sqrt(colsq[i])) : 1.0;
+    if (i < n) scale[i] = (!mask || mask[i]) ? 1.0 / (1.0 + sqrt(colsq[i])) : 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,42 +39,81 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+
 struct DiagLds {
     double D[SNB][SLD];                 // diagonal block / its factor (lower)
     double LT[SNB][SNB];                // LT[m][c] = L[c][m]: column m of L contiguous for wave-uniform wide reads
     double Inv[SNB];
-    double Col[2][SNB];
+    double W[SNB][SNB + 2];             // working copy for the factorisation: even stride = 16-byte aligned rows
 };
 struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
+    double Dn[SNB][SLD];                // next panel's diagonal block, handed over through LDS by the trailing update
     int Rows[SRMAX];
+    int Pi[SRMAX * (SRMAX + 1) / 2], Pj[SRMAX * (SRMAX + 1) / 2];     // block-pair list of the trailing update
 };
 
 // One wave (row = lane & 31): in-place Cholesky of the 32x32 block in s.D (lower), L' -> s.LT, 1/diag -> s.Inv.
+// LEFT-looking, the rows stay in LDS (working copy W, 16-byte aligned rows): pivot step j forms
+//     L[row][j] = (A[row][j] - sum_{m<j} L[row][m] L[j][m]) / L[j][j]
+// from the lane's own row (per-lane wide reads, conflict-free at stride 34) and row j (wave-uniform broadcast
+// reads), so the only registers are two accumulators.  The right-looking form with the row in registers
+// (32 or 2x16 doubles per lane) makes hipcc spill to scratch inside the pivot loop: measured 1400 cycles per step.
+// 1/sqrt(d) by v_rsq_f64 + two Newton steps (10 dependent ops; sqrt + divide expand to ~32 dependent fp64 ops,
+// which made the pivot chain ~1250 cycles per step)
+__device__ __forceinline__ double rsqrt_refined(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    double e = fma(-h * y, y, 0.5); y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5); y = fma(y, e, y);
+    return y;
+}
+
 __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 {
     const int row = lane & 31;
-    double a[SNB];
 #pragma unroll
-    for (int c = 0; c < SNB; ++c) a[c] = s.D[row][c];
+    for (int c = 0; c < SNB; ++c) s.W[row][c] = s.D[row][c];
+    wave_sync_lds();
     bool ok = true;
+    double part = s.W[row][0];          // column j's dot product over m <= j-2, prepared during step j-1
+    double prev = 0.0;                  // L[row][j-1], still in a register
 #pragma unroll
     for (int j = 0; j < SNB; ++j) {
-        const double d = readlane_f64(a[j], j);
+        // last term of the dot product straight from registers: L[row][j-1] * L[j][j-1] (lane j's previous result)
+        const double v = (j > 0) ? fma(-prev, readlane_f64(prev, j), part) : part;
+        const double d = readlane_f64(v, j);
         ok = ok && (d > 0.0) && (d < 1e300);
-        const double sd = sqrt(d > 0.0 ? d : 1.0), inv = 1.0 / sd;
-        a[j] = (row == j) ? sd : a[j] * inv;
-        s.Col[j & 1][row] = a[j];
-        s.LT[j][row] = a[j];
-        if (row == j) s.Inv[j] = inv;
-        wave_sync_lds();
+        const double dd = d > 0.0 ? d : 1.0;
+        const double y = rsqrt_refined(dd);
+        double sd = dd * y;
+        sd = fma(fma(-sd, sd, dd), 0.5 * y, sd);
+        const double lij = (row == j) ? sd : v * y;         // rows < j write garbage into the unused upper triangle
+        // meanwhile: column j+1 over m <= j-1 (every operand was published at least one step ago)
+        double nacc0 = 0.0, nacc1 = 0.0;
+        if (j + 1 < SNB) {
+            nacc0 = s.W[row][j + 1];
 #pragma unroll
-        for (int c = j + 1; c < SNB; ++c) a[c] -= a[j] * s.Col[j & 1][c];
+            for (int m = 0; m + 1 < j; m += 2) {
+                nacc0 -= s.W[row][m] * s.W[j + 1][m];
+                nacc1 -= s.W[row][m + 1] * s.W[j + 1][m + 1];
+            }
+            if (j & 1) nacc0 -= s.W[row][j - 1] * s.W[j + 1][j - 1];
+        }
+        s.W[row][j] = lij;
+        s.LT[j][row] = lij;
+        if (row == j) s.Inv[j] = y;
+        part = nacc0 + nacc1;
+        prev = lij;
+        wave_sync_lds();
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (lane < 32) {
 #pragma unroll
-        for (int c = 0; c < SNB; ++c) s.D[row][c] = (c <= row) ? a[c] : 0.0;
+        for (int c = 0; c < SNB; ++c) s.D[row][c] = (c <= row) ? s.W[row][c] : 0.0;
     }
     return ok;
 }
@@ -87,39 +126,90 @@ __device__ __forceinline__ void row_trsm32(double x[SNB], const DiagLds& s)
         x[m] *= s.Inv[m];
 #pragma unroll
         for (int c = m + 1; c < SNB; ++c) x[c] -= x[m] * s.LT[m][c];
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// prow_start[k] .. prow_start[k+1]: ascending block rows i > k with L_ik != 0 (after fill)
-__global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restrict__ A, int ld, int nb,
-                                                               const int* __restrict__ prow_start, const int* __restrict__ prow,
-                                                               double* __restrict__ rhs, double* __restrict__ y, int* __restrict__ err)
+// ------------------------------------------------------------------------------------------------
+// Panel sweeps shared by the kernels below.  prow_start[k] .. prow_start[k+1]: ascending block rows i > k with
+// L_ik != 0 (after fill).  Blocks >= top_blk form the "top" system (separators + intrinsics) shared by several
+// segment workgroups: updates whose target lies entirely in the top are accumulated in the caller's PRIVATE
+// buffers (topA: ntop x ntop, toprhs: ntop) and summed later in a fixed order (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------
+struct SolverPlan {
+    const int* prow_start; const int* prow;
+    int nb, top_blk;             // top_blk == nb: no shared top
+    int dbg;                     // timing experiments only (SFMHIP_EXP_SOLVER): skip phases, results are garbage
+    long long* stamps;           // diagnostic (SFMHIP_SOLVER_STAMPS): s_memtime at the phase boundaries of each panel, 8 per panel
+};
+
+template <bool HAS_TOP>
+__device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict__ A, int ld, int k0, int k1, const SolverPlan pl,
+                                               double* __restrict__ rhs, double* __restrict__ topA, double* __restrict__ toprhs)
 {
-    __shared__ SolverLds s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tid >> 5, c = tid & 31;
+    const int ntop = (pl.nb - pl.top_blk) * SNB;
     bool ok = true;
-
-    for (int k = 0; k < nb; ++k) {
-        const int p0 = prow_start[k], R = prow_start[k + 1] - p0;
-        if (tid < R) s.Rows[tid] = prow[p0 + tid];
-        for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k * SNB + r) * ld + k * SNB + c];
+    bool diag_in_lds = false;            // the previous panel's trailing update left this panel's diagonal block in s.Dn
+    constexpr int TT = 16;               // trailing tiles per wave whose old values are prefetched at the top of the panel
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k = k0; k < k1; ++k) {
+        const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
+        const int npairs = R * (R + 1) / 2, ntiles = npairs * 4;
+#define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+        STAMP(0);
+        if (tid < R) s.Rows[tid] = pl.prow[p0 + tid];
+        if (tid < npairs) { int qi = 0, rem = tid; while (rem > qi) { rem -= qi + 1; ++qi; } s.Pi[tid] = qi; s.Pj[tid] = rem; }
+        if (diag_in_lds) { for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = s.Dn[r][c]; }
+        else { for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k * SNB + r) * ld + k * SNB + c]; }
         __syncthreads();
+        STAMP(1);
+        // request the old values of this wave's first TT trailing-update tiles now: their latency hides behind the
+        // diagonal factorisation and the panel solve
+        v4d old[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const int T = wave + 4 * i;
+            if (T < ntiles && !(pl.dbg & 4)) {
+                const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+                const int bi = s.Rows[s.Pi[pr]], bjb = s.Rows[s.Pj[pr]];
+                const double* src; int dld;
+                if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+                else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
+                src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
+            }
+        }
         // wave 0 factors the diagonal block while waves 1.. stage the panel's row blocks and the rhs row
         if (wave > 0) {
-            for (int e = tid - 64; e < R * SNB * SNB; e += STHREADS - 64) {
-                const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31;
-                s.B[q * SNB + rr][cc] = A[(size_t)(s.Rows[q] * SNB + rr) * ld + k * SNB + cc];
+            // batches of 8 loads in flight per thread (a plain load->store loop pays one L2 round trip per element)
+            const int total = R * SNB * SNB;
+            for (int e0 = tid - 64; e0 < total && !(pl.dbg & 8); e0 += 8 * (STHREADS - 64)) {
+                double tmp[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + i * (STHREADS - 64);
+                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; tmp[i] = A[(size_t)(s.Rows[q] * SNB + rr) * ld + k * SNB + cc]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + i * (STHREADS - 64);
+                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; s.B[q * SNB + rr][cc] = tmp[i]; }
+                }
             }
             if (wave == 1 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
         } else {
-            ok = wave_chol32(s, lane) && ok;
+            if (!(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
+            STAMP(2);
         }
         __syncthreads();
+        STAMP(3);
         for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
         // panel rows x L^-T (one row per thread, registers)
         const int nrows = R * SNB + 1;
-        for (int t = tid; t < nrows; t += STHREADS) {
+        for (int t = tid; t < nrows && !(pl.dbg & 2); t += STHREADS) {
             double x[SNB];
 #pragma unroll
             for (int m = 0; m < SNB; ++m) x[m] = s.B[t][m];
@@ -131,44 +221,87 @@ __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restric
             for (int m = 0; m < SNB; ++m) g[m] = x[m];
         }
         __syncthreads();
-        // trailing update: A_ij -= L_ik L_jk' for the panel's block pairs, rhs_i -= L_ik z_k
-        for (int qi = 0; qi < R; ++qi)
-            for (int qj = 0; qj <= qi; ++qj) {
-                double acc[SNB / SROWS];
+        STAMP(4);
+        // trailing update: A_ij -= L_ik L_jk' for the panel's block pairs (fp64 MFMA 16x16x4: each 32x32 block pair is
+        // four 16x16 tiles x 8 k-steps), rhs_i -= L_ik z_k.  Tiles are dealt round-robin to the 4 waves; the old values
+        // of a whole chunk of target tiles are requested first (one memory latency per chunk, not per tile).
+        // Operand / result maps of v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+        // D[row = (l>>4) + 4*reg][col = l&15].
+        {
+            const bool next_diag = R > 0 && s.Rows[0] == k + 1 && k + 1 < k1;
+            for (int base = wave; base < ntiles && !(pl.dbg & 4); base += 4 * TT) {
+                if (base != wave) {          // beyond the prefetched chunk (wide panels only)
 #pragma unroll
-                for (int u = 0; u < SNB / SROWS; ++u) acc[u] = 0.0;
+                    for (int i = 0; i < TT; ++i) {
+                        const int T = base + 4 * i;
+                        if (T < ntiles) {
+                            const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+                            const int bi = s.Rows[s.Pi[pr]], bjb = s.Rows[s.Pj[pr]];
+                            const double* src; int dld;
+                            if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+                            else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
+                            src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
 #pragma unroll
-                for (int m = 0; m < SNB; ++m) {
-                    const double bj = s.B[qj * SNB + c][m];
-#pragma unroll
-                    for (int u = 0; u < SNB / SROWS; ++u) acc[u] += s.B[qi * SNB + r0 + u * SROWS][m] * bj;
+                            for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
+                        }
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < SNB / SROWS; ++u)
-                    A[(size_t)(s.Rows[qi] * SNB + r0 + u * SROWS) * ld + s.Rows[qj] * SNB + c] -= acc[u];
+                for (int i = 0; i < TT; ++i) {
+                    const int T = base + 4 * i;
+                    if (T < ntiles) {
+                        const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+                        const int qi = s.Pi[pr], qj = s.Pj[pr];
+                        v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s.B[qi * SNB + 16 * tr + li][4 * kk + lk],
+                                                                       s.B[qj * SNB + 16 * tc + li][4 * kk + lk], acc, 0, 0, 0);
+                        const int bi = s.Rows[qi], bjb = s.Rows[qj];
+                        double* dst; int dld;
+                        if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+                        else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
+                        dst += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const double v = old[i][g] - acc[g];
+                            dst[(size_t)(4 * g) * dld] = v;
+                            if (next_diag && pr == 0) s.Dn[16 * tr + lk + 4 * g][16 * tc + li] = v;     // pair 0 = (Rows[0], Rows[0])
+                        }
+                    }
+                }
             }
+            diag_in_lds = next_diag && !(pl.dbg & 4);
+        }
+        STAMP(5);
         for (int t = tid; t < R * SNB; t += STHREADS) {
             double v = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int m = 0; m < SNB; ++m) v += s.B[t][m] * s.B[R * SNB][m];
-            rhs[s.Rows[t >> 5] * SNB + (t & 31)] -= v;
+            const int bi = s.Rows[t >> 5];
+            if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] -= v;
+            else rhs[bi * SNB + (t & 31)] -= v;
         }
         __syncthreads();
+        STAMP(6);
     }
-    if (!ok && tid == 0) *err = 2;
+    return ok;
+}
 
-    // ---- backward: L' y = z (z now sits in rhs); y accumulates in LDS (aliases s.B)
-    double* sy = &s.B[0][0];
-    const int n = nb * SNB;
-    for (int i = tid; i < n; i += STHREADS) sy[i] = rhs[i];
-    __syncthreads();
-    for (int k = nb - 1; k >= 0; --k) {
-        const int p0 = prow_start[k], R = prow_start[k + 1] - p0;
+// L' y = z for panels k_hi-1 .. k_lo (descending); sy holds z for those panels and y for every later block they use
+__device__ __forceinline__ void backward_panels(SolverLds& s, const double* __restrict__ A, int ld, int k_lo, int k_hi,
+                                                const SolverPlan pl, double* sy)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = tid >> 5, c = tid & 31;
+    for (int k = k_hi - 1; k >= k_lo; --k) {
+        const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
         for (int r = r0; r < SNB; r += SROWS) {
             s.D[r][c] = A[(size_t)(k * SNB + r) * ld + k * SNB + c];
             double part = 0.0;
+#pragma unroll 4
             for (int q = 0; q < R; ++q) {
-                const int i = prow[p0 + q];
+                const int i = pl.prow[p0 + q];
                 part += A[(size_t)(i * SNB + r) * ld + k * SNB + c] * sy[i * SNB + r];
             }
             s.Red[r][c] = part;
@@ -190,5 +323,77 @@ __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restric
         }
         __syncthreads();
     }
+}
+
+// single workgroup: whole factorisation + both substitutions (no shared top)
+__global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restrict__ A, int ld, SolverPlan pl,
+                                                               double* __restrict__ rhs, double* __restrict__ y, int* __restrict__ err)
+{
+    __shared__ SolverLds s;
+    const int tid = threadIdx.x;
+    const bool ok = forward_panels<false>(s, A, ld, 0, pl.nb, pl, rhs, nullptr, nullptr);
+    if (!ok && tid == 0) *err = 2;
+    double* sy = &s.B[0][0];
+    const int n = pl.nb * SNB;
+    for (int i = tid; i < n; i += STHREADS) sy[i] = rhs[i];
+    __syncthreads();
+    backward_panels(s, A, ld, 0, pl.nb, pl, sy);
     for (int i = tid; i < n; i += STHREADS) y[i] = sy[i];
+}
+
+// ---- nested dissection over the camera chain: P segment workgroups, then one top workgroup, then P again -------
+// seg_blk[s] .. seg_blk[s+1]: panel range of segment s (block aligned); private top buffers: topbuf + s*(ntop^2 + ntop)
+__global__ __launch_bounds__(STHREADS) void chol_nd_forward_kernel(double* __restrict__ A, int ld, SolverPlan pl, const int* __restrict__ seg_blk,
+                                                                   double* __restrict__ rhs, double* __restrict__ topbuf, int* __restrict__ err)
+{
+    __shared__ SolverLds s;
+    const int seg = blockIdx.x;
+    const size_t ntop = (size_t)(pl.nb - pl.top_blk) * SNB;
+    double* topA = topbuf + (size_t)seg * (ntop * ntop + ntop);
+    const bool ok = forward_panels<true>(s, A, ld, seg_blk[seg], seg_blk[seg + 1], pl, rhs, topA, topA + ntop * ntop);
+    if (!ok && threadIdx.x == 0) *err = 2;
+}
+
+__global__ __launch_bounds__(STHREADS) void chol_nd_top_kernel(double* __restrict__ A, int ld, SolverPlan pl, int nseg,
+                                                               double* __restrict__ rhs, const double* __restrict__ topbuf,
+                                                               double* __restrict__ y, int* __restrict__ err)
+{
+    __shared__ SolverLds s;
+    const int tid = threadIdx.x;
+    const int ntop = (pl.nb - pl.top_blk) * SNB, t0 = pl.top_blk * SNB;
+    // fold the segments' private contributions into the top system, in segment order
+    for (int e = tid; e < ntop * ntop; e += STHREADS) {
+        const int i = e / ntop, j = e % ntop;
+        double v = A[(size_t)(t0 + i) * ld + t0 + j];
+        for (int sg = 0; sg < nseg; ++sg) v += topbuf[(size_t)sg * ((size_t)ntop * ntop + ntop) + e];
+        A[(size_t)(t0 + i) * ld + t0 + j] = v;
+    }
+    for (int i = tid; i < ntop; i += STHREADS) {
+        double v = rhs[t0 + i];
+        for (int sg = 0; sg < nseg; ++sg) v += topbuf[(size_t)sg * ((size_t)ntop * ntop + ntop) + (size_t)ntop * ntop + i];
+        rhs[t0 + i] = v;
+    }
+    __syncthreads();
+    SolverPlan top = pl; top.top_blk = pl.nb;
+    const bool ok = forward_panels<false>(s, A, ld, pl.top_blk, pl.nb, top, rhs, nullptr, nullptr);
+    if (!ok && tid == 0) *err = 2;
+    double* sy = &s.B[0][0];
+    for (int i = tid; i < ntop; i += STHREADS) sy[t0 + i] = rhs[t0 + i];
+    __syncthreads();
+    backward_panels(s, A, ld, pl.top_blk, pl.nb, pl, sy);
+    for (int i = tid; i < ntop; i += STHREADS) y[t0 + i] = sy[t0 + i];
+}
+
+__global__ __launch_bounds__(STHREADS) void chol_nd_backward_kernel(const double* __restrict__ A, int ld, SolverPlan pl, const int* __restrict__ seg_blk,
+                                                                    const double* __restrict__ rhs, double* __restrict__ y)
+{
+    __shared__ SolverLds s;
+    const int tid = threadIdx.x, seg = blockIdx.x;
+    const int k0 = seg_blk[seg], k1 = seg_blk[seg + 1];
+    double* sy = &s.B[0][0];
+    for (int i = pl.top_blk * SNB + tid; i < pl.nb * SNB; i += STHREADS) sy[i] = y[i];
+    for (int i = k0 * SNB + tid; i < k1 * SNB; i += STHREADS) sy[i] = rhs[i];
+    __syncthreads();
+    backward_panels(s, A, ld, k0, k1, pl, sy);
+    for (int i = k0 * SNB + tid; i < k1 * SNB; i += STHREADS) y[i] = sy[i];
 }
