@@ -151,6 +151,7 @@ struct sfmhip_ba {
     double *d_K = nullptr, *d_ext = nullptr, *d_pts = nullptr;
     double *d_Kc = nullptr, *d_extc = nullptr, *d_ptsc = nullptr;
     double *d_K0 = nullptr, *d_ext0 = nullptr, *d_pts0 = nullptr;
+    double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera R and dR/dw (36 doubles), current / candidate
     // structure
     int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_obs = nullptr;
     int *d_blk_cam = nullptr, *d_blk_start = nullptr, *d_items = nullptr;
@@ -207,6 +208,7 @@ static BADev make_dev(const sfmhip_ba* h, double radius)
     P.pt_start = h->d_pt_start; P.ocam = h->d_ocam; P.ouv = h->d_ouv;
     P.cam_start = h->d_cam_start; P.cam_obs = h->d_cam_obs; P.opt = h->d_opt;
     P.cam_pos = h->d_cam_pos; P.posmask = h->d_posmask;
+    P.campre = h->d_campre; P.campre_c = h->d_campre_c;
     P.scale_c = h->d_scale_c; P.scale_p = h->d_scale_p;
     P.Vinv = h->d_Vinv; P.bp = h->d_bp; P.WK = h->d_WK; P.colsq_p = h->d_colsq_p;
     const size_t np2 = (size_t)h->npad * h->npad;
@@ -233,6 +235,7 @@ static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp)
     BADev P = make_dev(h, radius);
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
+    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
     hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split), dim3(256), 0, st, P);
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
@@ -302,6 +305,7 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     hipStream_t st = ctx->stream;
     BADev P = make_dev(h, radius);
     hipLaunchKernelGGL(ba_camstep_kernel, dim3(1), dim3(256), 0, st, P, h->d_cam2);
+    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_extc, h->nc, h->d_campre_c);
     hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P);
     hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4);
     SFM_HIP_TRY(ctx, hipGetLastError());
@@ -651,6 +655,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_start, blk_start.data(), blk_start.size()));
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size()));
     TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
+    TRY_RC(dalloc(h, &h->d_campre, 36 * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, 36 * (size_t)n_cam));
     TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_seg_blk, 16));
     TRY_RC(dalloc(h, &h->d_prow_start, (size_t)h->npad_max / NB + 2)); TRY_RC(dalloc(h, &h->d_prow, ((size_t)h->npad_max / NB + 1) * SRMAX + 1));
     TRY_RC(dalloc(h, &h->d_Vinv, 6 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_bp, 3 * (size_t)n_pt));

@@ -31,6 +31,8 @@ struct BADev {
     // layout of the reduced system: position of camera c's 6 columns (-1 = constant camera), koff = intrinsics;
     // posmask[i] = 1 for a real parameter, 0 for a padding slot (segments are padded to whole 32-blocks)
     const int* cam_pos; const int* posmask;
+    // per-camera rotation matrix and its angle-axis derivatives (36 doubles: R, dR/dw0, dR/dw1, dR/dw2), current / candidate
+    const double* campre; const double* campre_c;
     // column scaling (cam side: npad entries; points: 3 np)
     const double* scale_c; const double* scale_p;
     // per point
@@ -60,52 +62,11 @@ struct ObsLin {
     double rho0;       // rho(|r|^2) (cost = 1/2 rho0)
 };
 
-__device__ __forceinline__ void project_point(const double* __restrict__ e, const double X[3], double p[3])
+// R(omega) X and its derivatives d(R X)/d omega_m for one vector X: ceres::AngleAxisRotatePoint [3P] including the
+// theta^2 <= DBL_EPSILON first-order branch.  Only ba_campre_kernel calls this (on the three unit vectors): the
+// observation kernels read the per-camera matrices instead of redoing sincos + the derivative chain per observation.
+__device__ __forceinline__ void rotate_with_derivs(const double* __restrict__ e, const double X[3], double p[3], double dpw[3][3])
 {
-    const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-    if (th2 > DBL_EPSILON) {
-        const double th = sqrt(th2);
-        double s, c; sincos(th, &s, &c);
-        const double inv = 1.0 / th;
-        const double w0 = e[0] * inv, w1 = e[1] * inv, w2 = e[2] * inv;
-        const double wx0 = w1 * X[2] - w2 * X[1], wx1 = w2 * X[0] - w0 * X[2], wx2 = w0 * X[1] - w1 * X[0];
-        const double tmp = (w0 * X[0] + w1 * X[1] + w2 * X[2]) * (1.0 - c);
-        p[0] = X[0] * c + wx0 * s + w0 * tmp;
-        p[1] = X[1] * c + wx1 * s + w1 * tmp;
-        p[2] = X[2] * c + wx2 * s + w2 * tmp;
-    } else {
-        p[0] = X[0] + (e[1] * X[2] - e[2] * X[1]);
-        p[1] = X[1] + (e[2] * X[0] - e[0] * X[2]);
-        p[2] = X[2] + (e[0] * X[1] - e[1] * X[0]);
-    }
-    p[0] += e[3]; p[1] += e[4]; p[2] += e[5];
-}
-
-__device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1)
-{
-    if (a > 0.0 && s > a * a) { const double r = sqrt(s); rho0 = 2.0 * a * r - a * a; rho1 = fmax(DBL_MIN, a / r); }
-    else { rho0 = s; rho1 = 1.0; }
-}
-
-// cost only: 1/2 rho(|r|^2)
-__device__ __forceinline__ double obs_cost(const double* __restrict__ K4, const double* __restrict__ e, const double X[3],
-                                           double u, double v, double huber_a)
-{
-    double p[3];
-    project_point(e, X, p);
-    const double r0 = K4[0] * (p[0] / p[2]) + K4[2] - u;
-    const double r1 = K4[1] * (p[1] / p[2]) + K4[3] - v;
-    double rho0, rho1;
-    huber_rho(huber_a, r0 * r0 + r1 * r1, rho0, rho1);
-    return 0.5 * rho0;
-}
-
-__device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, const double* __restrict__ e, const double X[3],
-                                              double u, double v, double huber_a,
-                                              const double* __restrict__ sK /*4 or null*/, const double* __restrict__ sc /*6 or null*/,
-                                              const double sp[3], ObsLin& o)
-{
-    double p[3], R[3][3], dpw[3][3];   // dpw[m][k] = d p_k / d omega_m
     const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
     if (th2 > DBL_EPSILON) {
         const double th = sqrt(th2);
@@ -117,10 +78,6 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
         const double omc = 1.0 - c, tmp = dot * omc;
 #pragma unroll
         for (int k = 0; k < 3; ++k) p[k] = X[k] * c + wx[k] * s + w[k] * tmp;
-        // R = c I + s [w]x + (1-c) w w'
-        R[0][0] = c + omc * w[0] * w[0];       R[0][1] = -s * w[2] + omc * w[0] * w[1]; R[0][2] = s * w[1] + omc * w[0] * w[2];
-        R[1][0] = s * w[2] + omc * w[1] * w[0]; R[1][1] = c + omc * w[1] * w[1];        R[1][2] = -s * w[0] + omc * w[1] * w[2];
-        R[2][0] = -s * w[1] + omc * w[2] * w[0]; R[2][1] = s * w[0] + omc * w[2] * w[1]; R[2][2] = c + omc * w[2] * w[2];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             double dw[3];
@@ -138,15 +95,67 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
         p[0] = X[0] + (e[1] * X[2] - e[2] * X[1]);
         p[1] = X[1] + (e[2] * X[0] - e[0] * X[2]);
         p[2] = X[2] + (e[0] * X[1] - e[1] * X[0]);
-        R[0][0] = 1.0;   R[0][1] = -e[2]; R[0][2] = e[1];
-        R[1][0] = e[2];  R[1][1] = 1.0;   R[1][2] = -e[0];
-        R[2][0] = -e[1]; R[2][1] = e[0];  R[2][2] = 1.0;
         // d(omega x X)/d omega_m = e_m x X
         dpw[0][0] = 0.0;   dpw[0][1] = -X[2]; dpw[0][2] = X[1];
         dpw[1][0] = X[2];  dpw[1][1] = 0.0;   dpw[1][2] = -X[0];
         dpw[2][0] = -X[1]; dpw[2][1] = X[0];  dpw[2][2] = 0.0;
     }
-    p[0] += e[3]; p[1] += e[4]; p[2] += e[5];
+}
+
+// pre[36] per camera: R row-major (9), then dR/dw_m row-major (9 each, m = 0..2)
+__global__ void ba_campre_kernel(const double* __restrict__ ext, int nc, double* __restrict__ pre)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    const double* e = ext + 6 * c;
+    double* o = pre + 36 * (size_t)c;
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+        const double X[3] = { col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0 };
+        double p[3], dpw[3][3];
+        rotate_with_derivs(e, X, p, dpw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[3 * k + col] = p[k];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) o[9 + 9 * m + 3 * k + col] = dpw[m][k];
+        }
+    }
+}
+
+__device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1)
+{
+    if (a > 0.0 && s > a * a) { const double r = sqrt(s); rho0 = 2.0 * a * r - a * a; rho1 = fmax(DBL_MIN, a / r); }
+    else { rho0 = s; rho1 = 1.0; }
+}
+
+// cost only: 1/2 rho(|r|^2); pre = the camera's 36-double block (only R is read), t = its translation
+__device__ __forceinline__ double obs_cost(const double* __restrict__ K4, const double* __restrict__ pre, const double* __restrict__ t,
+                                           const double X[3], double u, double v, double huber_a)
+{
+    const double p0 = pre[0] * X[0] + pre[1] * X[1] + pre[2] * X[2] + t[0];
+    const double p1 = pre[3] * X[0] + pre[4] * X[1] + pre[5] * X[2] + t[1];
+    const double p2 = pre[6] * X[0] + pre[7] * X[1] + pre[8] * X[2] + t[2];
+    const double r0 = K4[0] * (p0 / p2) + K4[2] - u;
+    const double r1 = K4[1] * (p1 / p2) + K4[3] - v;
+    double rho0, rho1;
+    huber_rho(huber_a, r0 * r0 + r1 * r1, rho0, rho1);
+    return 0.5 * rho0;
+}
+
+__device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, const double* __restrict__ pre, const double* __restrict__ t,
+                                              const double X[3], double u, double v, double huber_a,
+                                              const double* __restrict__ sK /*4 or null*/, const double* __restrict__ sc /*6 or null*/,
+                                              const double sp[3], ObsLin& o)
+{
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = pre[3 * i + j];
+    double p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = R[k][0] * X[0] + R[k][1] * X[1] + R[k][2] * X[2] + t[k];
     const double iz = 1.0 / p[2];
     const double x = p[0] * iz, y = p[1] * iz;
     double r0 = K4[0] * x + K4[2] - u;
@@ -169,8 +178,12 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
     if (sc) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            o.Ec[0][m] = (a00 * dpw[m][0] + a02 * dpw[m][2]) * sc[m];
-            o.Ec[1][m] = (a11 * dpw[m][1] + a12 * dpw[m][2]) * sc[m];
+            const double* d = pre + 9 + 9 * m;        // dR/dw_m
+            const double dp0 = d[0] * X[0] + d[1] * X[1] + d[2] * X[2];
+            const double dp1 = d[3] * X[0] + d[4] * X[1] + d[5] * X[2];
+            const double dp2 = d[6] * X[0] + d[7] * X[1] + d[8] * X[2];
+            o.Ec[0][m] = (a00 * dp0 + a02 * dp2) * sc[m];
+            o.Ec[1][m] = (a11 * dp1 + a12 * dp2) * sc[m];
         }
         o.Ec[0][3] = a00 * sc[3]; o.Ec[0][4] = 0.0;         o.Ec[0][5] = a02 * sc[5];
         o.Ec[1][3] = 0.0;         o.Ec[1][4] = a11 * sc[4]; o.Ec[1][5] = a12 * sc[5];
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
         for (int k = s0; k < s1; ++k) {
             const int c = P.ocam[k];
             ObsLin o;
-            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
+            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
                           P.fixK ? nullptr : P.scale_c + P.koff, nullptr, sp, o);
             cost += 0.5 * o.rho0;
             V[0] += o.F[0][0] * o.F[0][0] + o.F[1][0] * o.F[1][0];
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(256) void ba_camera_kernel(BADev P)
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         ObsLin o;
-        obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, sc, spp, o);
+        obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, sc, spp, o);
         double Vi[6], b[3], WK[12];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(BADev P, const int* __rest
         double T[6][3], W[6][3];
         {
             ObsLin o;
-            obs_linearize(P.K, P.ext + 6 * ca, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
+            obs_linearize(P.K, P.campre + 36 * (size_t)ca, P.ext + 6 * ca + 3, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 double w[3];
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(BADev P, const int* __rest
         }
         {
             ObsLin o;
-            obs_linearize(P.K, P.ext + 6 * cb, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
+            obs_linearize(P.K, P.campre + 36 * (size_t)cb, P.ext + 6 * cb + 3, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
         for (int k = s0; k < s1; ++k) {
             const int c = P.ocam[k], co = cam_off(P, c);
             ObsLin o;
-            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
+            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
             double e0 = 0.0, e1 = 0.0;
             if (co >= 0)
 #pragma unroll
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
         for (int k = s0; k < s1; ++k) {
             const int c = P.ocam[k], co = cam_off(P, c);
             ObsLin o;
-            obs_linearize(P.K, P.ext + 6 * c, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
+            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
             double m0 = 0.0, m1 = 0.0;
             if (co >= 0)
 #pragma unroll
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { m0 -= o.F[0][j] * yp[j]; m1 -= o.F[1][j] * yp[j]; }
             acc[0] -= m0 * (o.r[0] + 0.5 * m0) + m1 * (o.r[1] + 0.5 * m1);
-            acc[1] += obs_cost(P.Kc, P.extc + 6 * c, Xc, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a);
+            acc[1] += obs_cost(P.Kc, P.campre_c + 36 * (size_t)c, P.extc + 6 * c + 3, Xc, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
