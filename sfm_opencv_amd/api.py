@@ -274,7 +274,7 @@ class BAProblem:
         return S, rhs, cost.value
 
     def phase_ms(self):
-        out = (C.c_double * 4)()
+        out = (C.c_double * 8)()
         self.ctx._check(self.ctx.lib.sfmhip_ba_phase_ms(self.h, out))
         return list(out)
 

@@ -154,12 +154,13 @@ struct sfmhip_ba {
     double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera R and dR/dw (36 doubles), current / candidate
     // structure
     int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_obs = nullptr;
-    int *d_blk_cam = nullptr, *d_blk_start = nullptr, *d_items = nullptr;
+    int *d_blk_cam = nullptr, *d_blk_chunk = nullptr; int4 *d_items = nullptr, *d_chunk_desc = nullptr; int nchunk = 0; double* d_part_schur = nullptr;
     int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
     std::vector<int> host_blk_cam;
     // layout of the reduced system (nested-dissection ordering of the camera chain, segments padded to 32-blocks)
-    int npad_max = 0, nseg = 1, top_blk = 0;
+    int npad_max = 0, nseg = 1, top_blk = 0; long long nnz_blocks = 0;
     std::vector<int> cam_pos, pos_param;      // camera -> first position (-1 constant); position -> natural index (-1 pad)
+    std::vector<int> pt_slot;                 // caller's point index -> slot in the HBM arrays (points sorted by camera set)
     int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
     double* d_topbuf = nullptr; size_t topbuf_count = 0;
     double* d_ouv = nullptr;
@@ -176,8 +177,8 @@ struct sfmhip_ba {
     bool started = false;
     double radius = 0, nu = 2, x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0;
     int iter = 0, nsucc = 0, ninvalid = 0, termination = SFMHIP_BA_NO_CONVERGENCE;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    double phase_acc[4] = { 0, 0, 0, 0 }; int phase_cnt = 0;
+    hipEvent_t ev[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
 
 template <typename T>
@@ -228,7 +229,7 @@ static int call_allreduce(sfmhip_ba* h, double* buf, size_t count)
 }
 
 // linearise at the current parameters: message = [S | rhs | diagU | graw | scal], summed over ranks, damped.
-static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp)
+static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp, bool timed = false)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
@@ -237,10 +238,16 @@ static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp)
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
     hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
+    if (timed) (void)hipEventRecord(h->ev[4], st);
     hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split), dim3(256), 0, st, P);
+    if (timed) (void)hipEventRecord(h->ev[5], st);
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
-    if (h->nblk > 0)
-        hipLaunchKernelGGL(ba_schur_kernel, dim3(h->nblk), dim3(64), 0, st, P, h->d_blk_cam, h->d_blk_start, h->d_items);
+    if (timed) (void)hipEventRecord(h->ev[6], st);
+    if (h->nblk > 0) {
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(ceil_div(h->nchunk, 4)), dim3(256), 0, st, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
+    }
+    if (timed) (void)hipEventRecord(h->ev[7], st);
     SFM_HIP_TRY(ctx, hipGetLastError());
     int rc = call_allreduce(h, h->d_msg, h->msg_count); if (rc) return rc;
     if (damp) { hipLaunchKernelGGL(ba_damp_kernel, dim3(1), dim3(256), 0, st, P); SFM_HIP_TRY(ctx, hipGetLastError()); }
@@ -278,7 +285,9 @@ static int enqueue_solve(sfmhip_ba* h)
             hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, rhs_rw, h->d_y, h->d_err);
         } else {
             SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
+            (void)hipEventRecord(h->ev[8], st);
             hipLaunchKernelGGL(chol_nd_forward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_topbuf, h->d_err);
+            (void)hipEventRecord(h->ev[9], st);
             hipLaunchKernelGGL(chol_nd_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->nseg, rhs_rw, h->d_topbuf, h->d_y, h->d_err);
             hipLaunchKernelGGL(chol_nd_backward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_y);
         }
@@ -406,6 +415,7 @@ static int build_solver_plan(sfmhip_ba* h)
         }
         if (P > 1 && (!independent || maxR > SRMAX)) continue;       // retry with a single segment
         h->max_panel_rows = maxR;
+        h->nnz_blocks = (long long)rows.size() + nb;
         h->use_sparse = maxR <= SRMAX && npad <= (SRMAX * SNB + 1) * SLD;
         if (getenv("SFMHIP_DENSE_SOLVER")) h->use_sparse = false;
         // ---- upload
@@ -494,7 +504,7 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (h->iter >= it_end) { h->termination = SFMHIP_BA_NO_CONVERGENCE; break; }
         if (!forced && h->radius < o.min_trust_region_radius) { h->termination = SFMHIP_BA_CONVERGENCE; break; }
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev[0], st));
-        int rc = enqueue_linearize(h, h->radius, true); if (rc) return rc;
+        int rc = enqueue_linearize(h, h->radius, true, true); if (rc) return rc;
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev[1], st));
         rc = enqueue_solve(h); if (rc) return rc;
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev[2], st));
@@ -506,10 +516,13 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 8, h->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
         {
-            float a = 0, b = 0, c = 0;
+            float a = 0, b = 0, c = 0, k1 = 0, k2 = 0, k3 = 0;
             (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]); (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
             (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-            h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c; h->phase_cnt++;
+            (void)hipEventElapsedTime(&k1, h->ev[4], h->ev[5]); (void)hipEventElapsedTime(&k2, h->ev[6], h->ev[7]);
+            if (h->use_sparse && h->nseg > 1) (void)hipEventElapsedTime(&k3, h->ev[8], h->ev[9]);
+            h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c;
+            h->phase_acc[4] += k1; h->phase_acc[5] += k2; h->phase_acc[6] += k3; h->phase_cnt++;
         }
         const double cost = h->h_scal[0], gmax = h->h_scal[1], mcc = h->h_scal[2], cand_raw = h->h_scal[3];
         const double dn = h->h_scal[4] + h->h_scal[6], xn = h->h_scal[5] + h->h_scal[7];
@@ -607,12 +620,32 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->n_pt_blocks = std::max(1, ceil_div(n_pt, 256));
 
     // ---- orderings (host, once per problem)
+    // Points are stored sorted by the set of cameras that see them (lexicographic on the ascending camera list):
+    // every per-camera and per-camera-pair walk below then gathers from runs of neighbouring point records
+    // instead of from all over HBM (C4 on MI355X: linearisation 0.41 -> 0.31 ms, back-substitution 0.13 -> 0.08 ms).
+    // Internal only: sfmhip_ba_get_params hands the points back in the caller's order.
     std::vector<int> pt_start(n_pt + 1, 0), fill(n_pt, 0), ocam(n_obs), opt(n_obs), perm(n_obs);
     std::vector<double> ouv(2 * (size_t)n_obs);
-    for (int k = 0; k < n_obs; ++k) pt_start[obs_pt[k] + 1]++;
+    {
+        std::vector<int> st(n_pt + 1, 0), fl(n_pt, 0), cams(n_obs), order(n_pt);
+        for (int k = 0; k < n_obs; ++k) st[obs_pt[k] + 1]++;
+        for (int p = 0; p < n_pt; ++p) st[p + 1] += st[p];
+        for (int k = 0; k < n_obs; ++k) { const int p = obs_pt[k]; cams[st[p] + fl[p]++] = obs_cam[k]; }
+        for (int p = 0; p < n_pt; ++p) { std::sort(cams.begin() + st[p], cams.begin() + st[p + 1]); order[p] = p; }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return std::lexicographical_compare(cams.begin() + st[a], cams.begin() + st[a + 1], cams.begin() + st[b], cams.begin() + st[b + 1]);
+        });
+        h->pt_slot.assign(n_pt, 0);
+        for (int s = 0; s < n_pt; ++s) h->pt_slot[order[s]] = s;
+    }
+    const std::vector<int>& slot = h->pt_slot;
+    std::vector<double> pts_s(3 * (size_t)n_pt);
+    for (int p = 0; p < n_pt; ++p)
+        for (int d = 0; d < 3; ++d) pts_s[3 * (size_t)slot[p] + d] = pts[3 * (size_t)p + d];
+    for (int k = 0; k < n_obs; ++k) pt_start[slot[obs_pt[k]] + 1]++;
     for (int p = 0; p < n_pt; ++p) pt_start[p + 1] += pt_start[p];
-    for (int k = 0; k < n_obs; ++k) { const int p = obs_pt[k]; perm[pt_start[p] + fill[p]++] = k; }
-    for (int q = 0; q < n_obs; ++q) { const int k = perm[q]; ocam[q] = obs_cam[k]; opt[q] = obs_pt[k]; ouv[2 * (size_t)q] = obs_uv[2 * (size_t)k]; ouv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)k + 1]; }
+    for (int k = 0; k < n_obs; ++k) { const int p = slot[obs_pt[k]]; perm[pt_start[p] + fill[p]++] = k; }
+    for (int q = 0; q < n_obs; ++q) { const int k = perm[q]; ocam[q] = obs_cam[k]; opt[q] = slot[obs_pt[k]]; ouv[2 * (size_t)q] = obs_uv[2 * (size_t)k]; ouv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)k + 1]; }
     std::vector<int> cam_start(n_cam + 1, 0), cam_obs(n_obs), cfill(n_cam, 0);
     for (int q = 0; q < n_obs; ++q) cam_start[ocam[q] + 1]++;
     for (int c = 0; c < n_cam; ++c) cam_start[c + 1] += cam_start[c];
@@ -632,28 +665,36 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
                 items.push_back({ (long long)ci * n_cam + cj, qi, qj });
             }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
-    std::vector<int> blk_cam, blk_start, flat(2 * items.size());
-    for (size_t t = 0; t < items.size(); ++t) {
-        if (t == 0 || items[t].key != items[t - 1].key) {
-            blk_cam.push_back((int)(items[t].key / n_cam)); blk_cam.push_back((int)(items[t].key % n_cam));
-            blk_start.push_back((int)t);
-        }
-        flat[2 * t] = items[t].qi; flat[2 * t + 1] = items[t].qj;
+    int schur_chunk = 512;            // pairs per wave: 8 trips of the 64-lane loop, then one cross-lane reduction
+    if (const char* e = getenv("SFMHIP_SCHUR_CHUNK")) schur_chunk = std::max(64, atoi(e));
+    std::vector<int> blk_cam, blk_chunk;
+    std::vector<int4> flat(items.size()), chunk_desc;
+    for (size_t t = 0; t < items.size();) {
+        size_t u = t;
+        while (u < items.size() && items[u].key == items[t].key) ++u;
+        const int ca = (int)(items[t].key / n_cam), cb = (int)(items[t].key % n_cam);
+        blk_cam.push_back(ca); blk_cam.push_back(cb);
+        blk_chunk.push_back((int)chunk_desc.size());
+        const size_t cnt = u - t, nch = (cnt + schur_chunk - 1) / schur_chunk, per = round_up((int)((cnt + nch - 1) / nch), 64);
+        for (size_t a = t; a < u; a += per) chunk_desc.push_back(make_int4(ca, cb, (int)a, (int)std::min(u, a + per)));
+        for (; t < u; ++t) flat[t] = make_int4(items[t].qi, items[t].qj, opt[items[t].qi], 0);
     }
-    blk_start.push_back((int)items.size());
+    blk_chunk.push_back((int)chunk_desc.size());
     h->nblk = (int)blk_cam.size() / 2;
+    h->nchunk = (int)chunk_desc.size();
     h->host_blk_cam = blk_cam;
 
     int rc = SFMHIP_OK;
 #define TRY_RC(x) do { rc = (x); if (rc) { sfmhip_ba_destroy(h); return rc; } } while (0)
-    TRY_RC(dupload(h, &h->d_K, K4, 4)); TRY_RC(dupload(h, &h->d_ext, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_pts, pts, 3 * (size_t)n_pt));
-    TRY_RC(dupload(h, &h->d_K0, K4, 4)); TRY_RC(dupload(h, &h->d_ext0, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_pts0, pts, 3 * (size_t)n_pt));
-    TRY_RC(dupload(h, &h->d_Kc, K4, 4)); TRY_RC(dupload(h, &h->d_extc, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_ptsc, pts, 3 * (size_t)n_pt));
+    TRY_RC(dupload(h, &h->d_K, K4, 4)); TRY_RC(dupload(h, &h->d_ext, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_pts, pts_s.data(), 3 * (size_t)n_pt));
+    TRY_RC(dupload(h, &h->d_K0, K4, 4)); TRY_RC(dupload(h, &h->d_ext0, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_pts0, pts_s.data(), 3 * (size_t)n_pt));
+    TRY_RC(dupload(h, &h->d_Kc, K4, 4)); TRY_RC(dupload(h, &h->d_extc, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_ptsc, pts_s.data(), 3 * (size_t)n_pt));
     TRY_RC(dupload(h, &h->d_pt_start, pt_start.data(), pt_start.size())); TRY_RC(dupload(h, &h->d_ocam, ocam.data(), ocam.size()));
     TRY_RC(dupload(h, &h->d_opt, opt.data(), opt.size())); TRY_RC(dupload(h, &h->d_ouv, ouv.data(), ouv.size()));
     TRY_RC(dupload(h, &h->d_cam_start, cam_start.data(), cam_start.size())); TRY_RC(dupload(h, &h->d_cam_obs, cam_obs.data(), cam_obs.size()));
-    TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_start, blk_start.data(), blk_start.size()));
-    TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size()));
+    TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_chunk, blk_chunk.data(), blk_chunk.size()));
+    TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size())); TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));
+    TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));
     TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_campre, 36 * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, 36 * (size_t)n_cam));
     TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_seg_blk, 16));
@@ -690,7 +731,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ext, h->d_ext0, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (h->np) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts, h->d_pts0, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     h->started = false;
-    h->phase_acc[0] = h->phase_acc[1] = h->phase_acc[2] = h->phase_acc[3] = 0; h->phase_cnt = 0;
+    for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     return SFMHIP_OK;
 }
 
@@ -708,7 +749,7 @@ int sfmhip_ba_iterate(sfmhip_ba* h, int n_iter, sfm_ba_summary* summary)
 {
     if (!h || n_iter < 0) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
-    h->phase_acc[0] = h->phase_acc[1] = h->phase_acc[2] = h->phase_acc[3] = 0; h->phase_cnt = 0;
+    for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     const int rc = ba_loop(h, n_iter, true);
     fill_summary(h, summary, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;
@@ -721,7 +762,12 @@ int sfmhip_ba_get_params(sfmhip_ba* h, double* K4, double* ext6, double* pts)
     SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (K4) SFM_HIP_TRY(ctx, hipMemcpy(K4, h->d_K, 4 * sizeof(double), hipMemcpyDeviceToHost));
     if (ext6) SFM_HIP_TRY(ctx, hipMemcpy(ext6, h->d_ext, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToHost));
-    if (pts && h->np) SFM_HIP_TRY(ctx, hipMemcpy(pts, h->d_pts, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToHost));
+    if (pts && h->np) {
+        std::vector<double> tmp(3 * (size_t)h->np);
+        SFM_HIP_TRY(ctx, hipMemcpy(tmp.data(), h->d_pts, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int p = 0; p < h->np; ++p)
+            for (int d = 0; d < 3; ++d) pts[3 * (size_t)p + d] = tmp[3 * (size_t)h->pt_slot[p] + d];
+    }
     return SFMHIP_OK;
 }
 
@@ -750,10 +796,11 @@ int sfmhip_ba_reduced_system(sfmhip_ba* h, double radius, double* S, double* rhs
     return SFMHIP_OK;
 }
 
-int sfmhip_ba_phase_ms(sfmhip_ba* h, double out_ms[4])
+int sfmhip_ba_phase_ms(sfmhip_ba* h, double out_ms[8])
 {
     if (!h || !out_ms) return SFMHIP_E_ARG;
-    for (int i = 0; i < 4; ++i) out_ms[i] = h->phase_cnt ? h->phase_acc[i] / h->phase_cnt : 0.0;
+    for (int i = 0; i < 8; ++i) out_ms[i] = h->phase_cnt ? h->phase_acc[i] / h->phase_cnt : 0.0;
+    out_ms[7] = (double)h->nnz_blocks;
     return SFMHIP_OK;
 }
 

@@ -502,23 +502,28 @@ __global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_bloc
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_schur: one wave per camera-camera block (a, b), a >= b, over the list of observation pairs (i in a, j in b)
-// that share a point: block -= sum T_i W_j'.  a == b (i != j: one point seen twice by one camera) adds the
-// symmetrised term onto the diagonal block written by K_finalize.
+// K_schur: the observation pairs (i in camera a, j in camera b, a >= b) that share a point, sorted by (a, b), are cut
+// into chunks of <= SCHUR_CHUNK pairs; one wave per chunk accumulates sum T_i W_j' (6x6) and writes it as a partial.
+// K_schur_reduce sums each block's partials in chunk order (fixed order => run-to-run identical) and writes
+// S_ab = S_ba' = -sum; a == b (one point seen twice by one camera) adds the symmetrised term onto the diagonal
+// block written by K_finalize.  chunk_desc: [ca, cb, first item, end item]; items: [obs i, obs j, point, -].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ba_schur_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_start,
-                                                      const int* __restrict__ items)
+__global__ __launch_bounds__(256) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
+                                                       const int4* __restrict__ items, double* __restrict__ part)
 {
-    const int blk = blockIdx.x, lane = threadIdx.x;
-    const int ca = blk_cam[2 * blk], cb = blk_cam[2 * blk + 1];
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= n_chunk) return;
+    const int4 cd = chunk_desc[chunk];
+    const int ca = __builtin_amdgcn_readfirstlane(cd.x), cb = __builtin_amdgcn_readfirstlane(cd.y);
+    const int s0 = __builtin_amdgcn_readfirstlane(cd.z), s1 = __builtin_amdgcn_readfirstlane(cd.w);
     const int oa = cam_off(P, ca), ob = cam_off(P, cb);
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-    const int s0 = blk_start[blk], s1 = blk_start[blk + 1];
     for (int q = s0 + lane; q < s1; q += 64) {
-        const int ki = items[2 * q], kj = items[2 * q + 1];
-        const int p = P.opt[ki];
+        const int4 it = items[q];
+        const int ki = it.x, kj = it.y, p = it.z;
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         double Vi[6];
@@ -552,21 +557,30 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(BADev P, const int* __rest
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
     // lane q < 36 keeps element q (static selection, no dynamic register indexing)
-    double mine = 0.0, mineT = 0.0;
+    double mine = 0.0;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) {
+    for (int i = 0; i < 36; ++i)
         if (lane == i) mine = acc[i];
-        if (lane == (i % 6) * 6 + i / 6) mineT = acc[i];
-    }
-    if (lane < 36) {
-        const int i = lane / 6, j = lane % 6;
-        const int ld = P.npad;
-        if (ca != cb) {
-            P.S[(size_t)(oa + i) * ld + ob + j] = -mine;
-            P.S[(size_t)(ob + j) * ld + oa + i] = -mine;
-        } else {
-            P.S[(size_t)(oa + i) * ld + oa + j] -= mine + mineT;
-        }
+    if (lane < 36) part[36 * (size_t)chunk + lane] = mine;
+}
+
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
+                                                              int n_blk, const double* __restrict__ part)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int blk = t / 36, e = t % 36;
+    if (blk >= n_blk) return;
+    const int ca = blk_cam[2 * blk], cb = blk_cam[2 * blk + 1];
+    const int oa = cam_off(P, ca), ob = cam_off(P, cb);
+    const int i = e / 6, j = e % 6, eT = j * 6 + i;
+    double sum = 0.0, sumT = 0.0;
+    for (int c = blk_chunk[blk]; c < blk_chunk[blk + 1]; ++c) { sum += part[36 * (size_t)c + e]; sumT += part[36 * (size_t)c + eT]; }
+    const int ld = P.npad;
+    if (ca != cb) {
+        P.S[(size_t)(oa + i) * ld + ob + j] = -sum;
+        P.S[(size_t)(ob + j) * ld + oa + i] = -sum;
+    } else {
+        P.S[(size_t)(oa + i) * ld + oa + j] -= sum + sumT;
     }
 }
 

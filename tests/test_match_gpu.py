@@ -166,3 +166,14 @@ def test_device_resident_knn_and_forced_paths_agree(ctx):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     oi, od = orc.knn2_l2(descs[0], descs[1])
     assert np.array_equal(res[0][0], oi) and np.array_equal(res[0][1], od)
+
+
+def test_exact_sqrt_all_integers(ctx):
+    # the distance-matrix epilogue uses a short correctly-rounded sqrt valid for integer-valued floats < 2^24:
+    # exhaustive device-side comparison with sqrtf
+    import ctypes as C
+    n = C.c_int(-1)
+    fn = ctx.lib.sfmhip_debug_sqrt_check
+    fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert fn(ctx.h, C.byref(n)) == 0
+    assert n.value == 0
