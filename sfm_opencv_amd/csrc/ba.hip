@@ -37,15 +37,11 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, i
     if (lane < 32)
 #pragma unroll
         for (int c = 0; c < NB; ++c) base[(size_t)row * ld + c] = s.D[row][c];
-    // X = L^-1: row i of X is e_i L^-T ... computed as x L^-T with x = e_row, i.e. lane = row of L^-T = column of L^-1
-    double x[NB];
-#pragma unroll
-    for (int m = 0; m < NB; ++m) x[m] = (m == row) ? 1.0 : 0.0;
-    row_trsm32(x, s);                      // x = e_row L^-T  =>  x[c] = (L^-1)[c][row]
+    // L^-1 came out of the same pivot loop, one column per row of s.W[32..63]
     if (lane < 32) {
         double* out = Linv + (size_t)k * NB * NB;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) out[i * NB + row] = x[i];
+        for (int i = 0; i < NB; ++i) out[i * NB + row] = s.W[NB + row][i];
     }
 }
 
@@ -267,16 +263,17 @@ static int enqueue_solve(sfmhip_ba* h)
         static long long* d_stamps = nullptr; static int stamp_calls = 0;
         pl.stamps = nullptr;
         if (getenv("SFMHIP_SOLVER_STAMPS")) {
-            if (!d_stamps) { (void)hipMalloc((void**)&d_stamps, 8 * 512 * sizeof(long long)); (void)hipMemset(d_stamps, 0, 8 * 512 * sizeof(long long)); }
+            if (!d_stamps) { (void)hipMalloc((void**)&d_stamps, 16 * 512 * sizeof(long long)); (void)hipMemset(d_stamps, 0, 16 * 512 * sizeof(long long)); }
             pl.stamps = d_stamps;
             if (++stamp_calls == 8) {          // dump once, after a few warm iterations
                 (void)hipStreamSynchronize(st);
-                std::vector<long long> hs(8 * (size_t)nb);
+                std::vector<long long> hs(16 * (size_t)nb);
                 (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 for (int k = 0; k < nb; ++k) {
                     fprintf(stderr, "[stamps] panel %3d:", k);
-                    for (int i = 1; i <= 6; ++i) fprintf(stderr, " %7lld", hs[8 * k + i] - hs[8 * k + i - 1]);
-                    fprintf(stderr, "   (load+sync | prefetch..chol | sync | trsm+sync | trailing | rhs+sync) x10ns\n");
+                    for (int i = 1; i <= 6; ++i) fprintf(stderr, " %7lld", hs[16 * k + i] - hs[16 * k + i - 1]);
+                    fprintf(stderr, " | prefetch %lld chol %lld", hs[16 * k + 7] - hs[16 * k + 1], hs[16 * k + 2] - hs[16 * k + 7]);
+                    fprintf(stderr, "   (load+sync | prefetch..chol | sync | trsm+sync | trailing | rhs+sync) cycles\n");
                 }
             }
         }

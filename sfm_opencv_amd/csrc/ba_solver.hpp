@@ -25,6 +25,9 @@
 #define SRMAX 8         // max sub-diagonal blocks per panel for the single-workgroup path
 #define STHREADS 256    // 4 waves, one per SIMD: the full register file for the unrolled 32-double register rows
 #define SROWS (STHREADS / 32)
+#ifndef SPW
+#define SPW 16          // panel width of the 32x32 pivot-block factorisation (columns a lane keeps in registers)
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
@@ -43,9 +46,10 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct DiagLds {
     double D[SNB][SLD];                 // diagonal block / its factor (lower)
-    double LT[SNB][SNB];                // LT[m][c] = L[c][m]: column m of L contiguous for wave-uniform wide reads
-    double Inv[SNB];
-    double W[SNB][SNB + 2];             // working copy for the factorisation: even stride = 16-byte aligned rows
+    // working copy for the factorisation, 16-byte aligned rows (even stride).  Rows 0..31: L.  Rows 32..63: the inverse,
+    // one COLUMN per row: W[32 + c][m] = (L^-1)[m][c] -- i.e. read as a 32x32 array it is (L^-1)', the operand X = B (L^-1)' needs.
+    double W[2 * SNB][SNB + 2];
+    double G[2 * SNB][SPW + 2];         // one panel of the cross-panel update, handed from the MFMA result layout to lane = row
 };
 struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
@@ -55,14 +59,22 @@ struct SolverLds : DiagLds {
     int Pi[SRMAX * (SRMAX + 1) / 2], Pj[SRMAX * (SRMAX + 1) / 2];     // block-pair list of the trailing update
 };
 
-// One wave (row = lane & 31): in-place Cholesky of the 32x32 block in s.D (lower), L' -> s.LT, 1/diag -> s.Inv.
-// LEFT-looking, the rows stay in LDS (working copy W, 16-byte aligned rows): pivot step j forms
-//     L[row][j] = (A[row][j] - sum_{m<j} L[row][m] L[j][m]) / L[j][j]
-// from the lane's own row (per-lane wide reads, conflict-free at stride 34) and row j (wave-uniform broadcast
-// reads), so the only registers are two accumulators.  The right-looking form with the row in registers
-// (32 or 2x16 doubles per lane) makes hipcc spill to scratch inside the pivot loop: measured 1400 cycles per step.
-// 1/sqrt(d) by v_rsq_f64 + two Newton steps (10 dependent ops; sqrt + divide expand to ~32 dependent fp64 ops,
-// which made the pivot chain ~1250 cycles per step)
+// One wave: in-place Cholesky of the 32x32 block in s.D (lower) AND the inverse of the factor, in the same 32 pivot steps:
+//     L[i][j] = (A[i][j] - sum_{m<j} L[i][m] L[j][m]) / L[j][j]                       lanes i = 0..31
+//     Z[j][c] = (I[j][c] - sum_{m<j} L[j][m] Z[m][c]) / L[j][j],  Z = L^-1            lanes 32 + c
+// Both are "own row . row j of L": one instruction stream, the upper half-wave starts from the identity instead of A
+// and its row 32 + c ends up holding column c of L^-1.
+// Two panels of SPW = 16 columns.  Inside a panel the lane keeps its 16 entries in registers and the pivot steps are
+// right-looking with v_readlane broadcasts: no LDS on the dependent chain (readlane -> rsqrt + Newton -> scale ->
+// readlane -> fma: ~20 dependent fp64 ops at ~16 cycles each; the other columns' updates fill its issue gaps).
+// Across panels the sum over the finished columns m < p is one small product W[:, :p] W[p:p+16, :p]' on the fp64
+// MFMA (operands requested up front), handed back to lane = row through s.G.  (8-column panels: three MFMA phases
+// cost 8.7k of 20k cycles; one 32-column panel: the early steps become issue-bound.)
+// History (cycles per 32x32 block at C4, in-kernel): sqrt + divide, rows in registers with scratch spills 45k;
+// left-looking with LDS rows 23k (+19.5k for the per-row substitutions the inverse now replaces); this form: see
+// profiles/README.md.
+// 1/sqrt(d) by v_rsq_f64 + two Newton steps (10 dependent ops; sqrt + divide expand to ~32 dependent fp64 ops).
+// The panel solve is then X = B (L^-1)' on the fp64 MFMA instead of a 32-step substitution per row.
 __device__ __forceinline__ double rsqrt_refined(double d)
 {
     double y = __builtin_amdgcn_rsq(d);
@@ -72,62 +84,74 @@ __device__ __forceinline__ double rsqrt_refined(double d)
     return y;
 }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 {
-    const int row = lane & 31;
-#pragma unroll
-    for (int c = 0; c < SNB; ++c) s.W[row][c] = s.D[row][c];
-    wave_sync_lds();
+    const bool lower = lane < SNB;
+    const int ident = lane - SNB;                           // upper half-wave: column index of L^-1
+    const int li = lane & 15, lk = lane >> 4;
+    const double* dr = &s.D[lane & (SNB - 1)][0];
     bool ok = true;
-    double part = s.W[row][0];          // column j's dot product over m <= j-2, prepared during step j-1
-    double prev = 0.0;                  // L[row][j-1], still in a register
 #pragma unroll
-    for (int j = 0; j < SNB; ++j) {
-        // last term of the dot product straight from registers: L[row][j-1] * L[j][j-1] (lane j's previous result)
-        const double v = (j > 0) ? fma(-prev, readlane_f64(prev, j), part) : part;
-        const double d = readlane_f64(v, j);
-        ok = ok && (d > 0.0) && (d < 1e300);
-        const double dd = d > 0.0 ? d : 1.0;
-        const double y = rsqrt_refined(dd);
-        double sd = dd * y;
-        sd = fma(fma(-sd, sd, dd), 0.5 * y, sd);
-        const double lij = (row == j) ? sd : v * y;         // rows < j write garbage into the unused upper triangle
-        // meanwhile: column j+1 over m <= j-1 (every operand was published at least one step ago)
-        double nacc0 = 0.0, nacc1 = 0.0;
-        if (j + 1 < SNB) {
-            nacc0 = s.W[row][j + 1];
+    for (int b = 0; b < SNB / SPW; ++b) {
+        const int p = SPW * b;
+        double x[SPW];
 #pragma unroll
-            for (int m = 0; m + 1 < j; m += 2) {
-                nacc0 -= s.W[row][m] * s.W[j + 1][m];
-                nacc1 -= s.W[row][m + 1] * s.W[j + 1][m + 1];
+        for (int c = 0; c < SPW; ++c) x[c] = lower ? dr[p + c] : (ident == p + c ? 1.0 : 0.0);
+        if (b > 0) {
+            // G = W[:, :p] W[p:p+SPW, :p]'  (64 x SPW; SPW < 16: the MFMA's surplus columns repeat and are dropped)
+            double bop[SNB / 4], aop[4][SNB / 4];
+#pragma unroll
+            for (int kk = 0; kk < p / 4; ++kk) {
+                bop[kk] = s.W[p + (li & (SPW - 1))][4 * kk + lk];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) aop[rt][kk] = s.W[16 * rt + li][4 * kk + lk];
             }
-            if (j & 1) nacc0 -= s.W[row][j - 1] * s.W[j + 1][j - 1];
-        }
-        s.W[row][j] = lij;
-        s.LT[j][row] = lij;
-        if (row == j) s.Inv[j] = y;
-        part = nacc0 + nacc1;
-        prev = lij;
-        wave_sync_lds();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (lane < 32) {
+            v4d acc[4];
 #pragma unroll
-        for (int c = 0; c < SNB; ++c) s.D[row][c] = (c <= row) ? s.W[row][c] : 0.0;
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = v4d{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int kk = 0; kk < p / 4; ++kk)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[rt][kk], bop[kk], acc[rt], 0, 0, 0);
+            if (li < SPW) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s.G[16 * rt + lk + 4 * g][li] = acc[rt][g];
+            }
+            wave_sync_lds();
+#pragma unroll
+            for (int c = 0; c < SPW; c += 2) { const v2d t = *(const v2d*)&s.G[lane][c]; x[c] -= t.x; x[c + 1] -= t.y; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < SPW; ++jj) {
+            const int j = p + jj;
+            const double d = readlane_f64(x[jj], j);
+            ok = ok && (d > 0.0) && (d < 1e300);            // d <= 0: NaNs from here on, the caller rejects the factor
+            const double y = rsqrt_refined(d);
+            const double l = x[jj] * y;                     // lane j: d / sqrt(d)
+            x[jj] = l;
+#pragma unroll
+            for (int c = jj + 1; c < SPW; ++c) x[c] = fma(-l, readlane_f64(l, p + c), x[c]);
+        }
+        // above the diagonal of L (upper half-wave: lane >= 32 > j): zero, off the pivot chain
+#pragma unroll
+        for (int c = 0; c < SPW; ++c) x[c] = (lane < p + c) ? 0.0 : x[c];
+#pragma unroll
+        for (int c = 0; c < SPW; c += 2) *(v2d*)&s.W[lane][p + c] = v2d{ x[c], x[c + 1] };
+        wave_sync_lds();
+    }
+    if (lower) {
+        v2d t[SNB / 2];                 // all reads first: interleaved with the stores the compiler waits after every one
+        const double* wr = &s.W[lane][0];
+#pragma unroll
+        for (int c = 0; c < SNB / 2; ++c) t[c] = *(const v2d*)(wr + 2 * c);
+#pragma unroll
+        for (int c = 0; c < SNB / 2; ++c) { s.D[lane][2 * c] = t[c].x; s.D[lane][2 * c + 1] = t[c].y; }
     }
     return ok;
-}
-
-// x <- x L^-T for one row held in registers (column-oriented substitution)
-__device__ __forceinline__ void row_trsm32(double x[SNB], const DiagLds& s)
-{
-#pragma unroll
-    for (int m = 0; m < SNB; ++m) {
-        x[m] *= s.Inv[m];
-#pragma unroll
-        for (int c = m + 1; c < SNB; ++c) x[c] -= x[m] * s.LT[m][c];
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,7 +181,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     for (int k = k0; k < k1; ++k) {
         const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
         const int npairs = R * (R + 1) / 2, ntiles = npairs * 4;
-#define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
         STAMP(0);
         if (tid < R) s.Rows[tid] = pl.prow[p0 + tid];
         if (tid < npairs) { int qi = 0, rem = tid; while (rem > qi) { rem -= qi + 1; ++qi; } s.Pi[tid] = qi; s.Pj[tid] = rem; }
@@ -182,6 +206,8 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
             }
         }
+        STAMP(7);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above: mixed into the factorisation it cost 20k cycles per panel
         // wave 0 factors the diagonal block while waves 1.. stage the panel's row blocks and the rhs row
         if (wave > 0) {
             // batches of 8 loads in flight per thread (a plain load->store loop pays one L2 round trip per element)
@@ -207,18 +233,28 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         __syncthreads();
         STAMP(3);
         for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
-        // panel rows x L^-T (one row per thread, registers)
+        // panel rows x L^-T = B (L^-1)' on the fp64 MFMA: one 16-row tile per wave at a time, both 16-column halves
+        // (columns < 16 only see k < 16: L^-1 is lower triangular).  The tile's operand rows are in registers before
+        // the results overwrite them; tiles of different waves touch disjoint rows.
         const int nrows = R * SNB + 1;
-        for (int t = tid; t < nrows && !(pl.dbg & 2); t += STHREADS) {
-            double x[SNB];
+        for (int rt = wave; rt * 16 < nrows && !(pl.dbg & 2); rt += 4) {
+            double a[8];
 #pragma unroll
-            for (int m = 0; m < SNB; ++m) x[m] = s.B[t][m];
-            row_trsm32(x, s);
+            for (int kk = 0; kk < 8; ++kk) a[kk] = s.B[16 * rt + li][4 * kk + lk];        // rows past nrows: stale LDS, results dropped
+            v4d x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int m = 0; m < SNB; ++m) s.B[t][m] = x[m];
-            double* g = (t < R * SNB) ? A + (size_t)(s.Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB : rhs + k * SNB;
+            for (int kk = 0; kk < 4; ++kk) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], s.W[SNB + 4 * kk + lk][li], x0, 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < SNB; ++m) g[m] = x[m];
+            for (int kk = 0; kk < 8; ++kk) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], s.W[SNB + 4 * kk + lk][16 + li], x1, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = 16 * rt + lk + 4 * g;
+                if (t < nrows) {
+                    s.B[t][li] = x0[g]; s.B[t][16 + li] = x1[g];
+                    double* gp = (t < R * SNB) ? A + (size_t)(s.Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB : rhs + k * SNB;
+                    gp[li] = x0[g]; gp[16 + li] = x1[g];
+                }
+            }
         }
         __syncthreads();
         STAMP(4);
