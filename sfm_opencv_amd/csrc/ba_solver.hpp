@@ -42,6 +42,15 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store
+// (vmcnt(0)), a full L2 round trip, which the panel loop can only afford once per panel
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct DiagLds {
@@ -206,6 +215,12 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
             }
         }
+        // ... and of the right-hand-side entries this thread updates at the end of the panel
+        double rhs_old = 0.0;
+        if (tid < R * SNB) {
+            const int bi = s.Rows[tid >> 5];
+            rhs_old = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (tid & 31)] : rhs[bi * SNB + (tid & 31)];
+        }
         STAMP(7);
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above: mixed into the factorisation it cost 20k cycles per panel
         // wave 0 factors the diagonal block while waves 1.. stage the panel's row blocks and the rhs row
@@ -230,7 +245,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             if (!(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
             STAMP(2);
         }
-        __syncthreads();
+        lds_barrier();                      // staged rows, L_kk and its inverse: all in LDS
         STAMP(3);
         for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
         // panel rows x L^-T = B (L^-1)' on the fp64 MFMA: one 16-row tile per wave at a time, both 16-column halves
@@ -256,7 +271,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();                      // the solved rows went to LDS; their global copies are not read again in this kernel
         STAMP(4);
         // trailing update: A_ij -= L_ik L_jk' for the panel's block pairs (fp64 MFMA 16x16x4: each 32x32 block pair is
         // four 16x16 tiles x 8 k-steps), rhs_i -= L_ik z_k.  Tiles are dealt round-robin to the 4 waves; the old values
@@ -310,13 +325,13 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             diag_in_lds = next_diag && !(pl.dbg & 4);
         }
         STAMP(5);
-        for (int t = tid; t < R * SNB; t += STHREADS) {
+        if (tid < R * SNB) {                 // R <= SRMAX = STHREADS / 32: one entry per thread
             double v = 0.0;
 #pragma unroll 8
-            for (int m = 0; m < SNB; ++m) v += s.B[t][m] * s.B[R * SNB][m];
-            const int bi = s.Rows[t >> 5];
-            if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] -= v;
-            else rhs[bi * SNB + (t & 31)] -= v;
+            for (int m = 0; m < SNB; ++m) v += s.B[tid][m] * s.B[R * SNB][m];
+            const int bi = s.Rows[tid >> 5];
+            if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (tid & 31)] = rhs_old - v;
+            else rhs[bi * SNB + (tid & 31)] = rhs_old - v;
         }
         __syncthreads();
         STAMP(6);

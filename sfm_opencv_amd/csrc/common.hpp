@@ -80,7 +80,7 @@ struct sfmhip_descset {
     const float* d_f32 = nullptr; size_t ld = 0; bool owns_f32 = false;
     int dim_pad = 0;                  // multiple of 32 (int8 copy row length in bytes)
     int8_t* d_i8 = nullptr;           // rows_pad x dim_pad, value - 128; pad rows zero
-    int32_t* d_norm = nullptr;        // rows_pad: sum (value-128)^2; pad rows = PAD_NORM
+    int32_t* d_norm = nullptr;        // 2 x rows_pad: [sum b^2 | sum b^2 + 2 sum b], b = value - 128; pad rows = PAD_NORM
     int exact_u8 = 0;                 // every value an integer in [0,255] and dim <= 128
     // Hamming2
     uint32_t* d_u32 = nullptr;        // rows_pad x 16 words (64 B rows, zero padded)

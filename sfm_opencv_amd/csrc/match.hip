@@ -28,34 +28,51 @@ typedef float v4f  __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // descriptor preparation
 // ------------------------------------------------------------------------------------------------
-// one wave per row: exactness check (integer in [0,255]), int8 copy (v-128, zero padded), squared norm
+// Float rows -> biased int8 rows (b = v - 128, zero padded), exactness check (integers in [0,255]) and two per-row
+// terms: norm[row] = sum b^2 and norm[rows_pad + row] = sum b^2 + 2 sum b (the train-side term of the kNN keys, see
+// knn2_i8_kernel).  Each lane converts 4 consecutive values (one 16-byte load, one 4-byte store); a wave covers
+// 64 / (dim_pad / 4) rows.
+__device__ __forceinline__ void prep_l2_rows(const float* __restrict__ src, size_t ld, int rows, int dim, int dim_pad, int rows_pad,
+                                             int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int wave_index)
+{
+    const int lane = threadIdx.x & 63;
+    const int lpr = dim_pad >> 2;                       // lanes per row: 8, 16 or 32
+    const int row = wave_index * (64 / lpr) + lane / lpr, k = (lane % lpr) * 4;
+    if (row >= rows_pad) return;
+    int acc = 0, sum = 0, bad = 0;
+    int packed = 0;
+    if (row < rows) {
+        float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const float* rp = src + (size_t)row * ld + k;
+        if (k + 3 < dim && ((((size_t)rp) & 15) == 0)) { const float4 t = *(const float4*)rp; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (k + i < dim) v[i] = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (k + i < dim) {
+                const float r = rintf(v[i]);
+                if (!(v[i] >= 0.0f && v[i] <= 255.0f) || r != v[i]) bad = 1;
+                const int q = (int)fminf(fmaxf(r, 0.0f), 255.0f) - 128;
+                packed |= (q & 255) << (8 * i);
+                acc += q * q; sum += q;
+            }
+        }
+    }
+    *(int*)(dst + (size_t)row * dim_pad + k) = packed;
+    for (int off = lpr >> 1; off > 0; off >>= 1) { acc += __shfl_xor(acc, off); sum += __shfl_xor(sum, off); }
+    if (lane % lpr == 0) {
+        norm[row] = row < rows ? acc : PAD_NORM;
+        norm[rows_pad + row] = row < rows ? acc + 2 * sum : PAD_NORM;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 __global__ void prep_l2_kernel(const float* __restrict__ src, size_t ld, int rows, int dim, int dim_pad,
                                int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int rows_pad)
 {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows_pad) return;
-    if (row >= rows) {
-        for (int k = lane; k < dim_pad; k += 64) dst[(size_t)row * dim_pad + k] = 0;
-        if (lane == 0) norm[row] = PAD_NORM;
-        return;
-    }
-    int acc = 0, bad = 0;
-    for (int k = lane; k < dim_pad; k += 64) {
-        int8_t o = 0;
-        if (k < dim) {
-            const float v = src[(size_t)row * ld + k];
-            const float r = rintf(v);
-            if (!(v >= 0.0f && v <= 255.0f) || r != v) bad = 1;
-            const int q = (int)fminf(fmaxf(r, 0.0f), 255.0f) - 128;
-            o = (int8_t)q;
-            acc += q * q;
-        }
-        dst[(size_t)row * dim_pad + k] = o;
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) norm[row] = acc;
-    if (bad) atomicOr(flag, 1);
+    prep_l2_rows(src, ld, rows, dim, dim_pad, rows_pad, dst, norm, flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
 // batched form: one launch prepares many images (blockIdx.y = image)
@@ -63,30 +80,7 @@ struct PrepDesc { const float* src; size_t ld; int rows, dim, dim_pad, rows_pad;
 __global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl)
 {
     const PrepDesc d = tbl[blockIdx.y];
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= d.rows_pad) return;
-    if (row >= d.rows) {
-        for (int k = lane; k < d.dim_pad; k += 64) d.dst[(size_t)row * d.dim_pad + k] = 0;
-        if (lane == 0) d.norm[row] = PAD_NORM;
-        return;
-    }
-    int acc = 0, bad = 0;
-    for (int k = lane; k < d.dim_pad; k += 64) {
-        int8_t o = 0;
-        if (k < d.dim) {
-            const float v = d.src[(size_t)row * d.ld + k];
-            const float r = rintf(v);
-            if (!(v >= 0.0f && v <= 255.0f) || r != v) bad = 1;
-            const int q = (int)fminf(fmaxf(r, 0.0f), 255.0f) - 128;
-            o = (int8_t)q;
-            acc += q * q;
-        }
-        d.dst[(size_t)row * d.dim_pad + k] = o;
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) d.norm[row] = acc;
-    if (bad) atomicOr(d.flag, 1);
+    prep_l2_rows(d.src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, d.dst, d.norm, d.flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
 // Hamming: copy rows into 64-byte zero-padded rows (16 dwords)
@@ -105,7 +99,7 @@ __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, 
 struct PairDesc {
     const void* q; const void* t;          // int8 (mfma path) / u32 rows (hamming)
     const float* qf; const float* tf;      // float rows (exact path)
-    const int32_t* qn; const int32_t* tn;  // squared norms of the biased int8 rows
+    const int32_t* qn; const int32_t* tn;  // query: sum a^2; train: sum b^2 + 2 sum b (biased int8 rows a, b)
     int nq, nt, nq_pad, nt_pad, dim;
     int nchunks, chunk_rows;               // train chunking (chunk_rows multiple of 128)
     long long part_off;                    // offset (entries of two keys) into the partial buffer, [row][chunk]
@@ -141,7 +135,8 @@ __global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict
     constexpr int DP = 32 * KS;          // bytes per row
     constexpr int CH = DP / 16;          // 16-byte chunks per row
     constexpr int PASSES = (128 * CH) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4];
+    constexpr int STAGE_BYTES = 2 * 128 * DP + 2 * 128 * 4, MERGE_BYTES = 4 * 32 * 33 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
     const PairDesc pd = pairs[blockIdx.z];
     const int qb = blockIdx.x, chunk = blockIdx.y;
     if (qb * 128 >= pd.nq_pad || chunk >= pd.nchunks) return;
@@ -154,11 +149,15 @@ __global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict
     const int nblocks = (t_end - t_begin) / 128;
     const int q0 = qb * 128 + wave * 32;
 
-    // stationary operand: 32 query rows per wave, lane holds row l31, k bytes [32 ks + 16 half, +16)
+    // stationary operand: 32 query rows per wave, lane holds row l31, k bytes [32 ks + 16 half, +16), COMPLEMENTED:
+    // ~a = -a - 1 stays in int8 range, and with S = sum (~a) b = -a.b - sum b the partial key
+    //     (|b|^2 - 2 a.b) * 128 + slot = (|b|^2 + 2 sum b) * 128 + slot + (S << 8)
+    // is one v_lshl_add_u32 per accumulator (the train-side term comes from the prep kernel).  Zero padding stays
+    // neutral: padded query bytes become -1 but meet zero train bytes.
     v4i afrag[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        afrag[ks] = *(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
+        afrag[ks] = ~*(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
 
     int best1[16], best2[16];
 #pragma unroll
@@ -199,13 +198,16 @@ __global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict
                 const v4i b = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], b, acc, 0, 0, 0);
             }
-            // C[row = query (reg), col = train (lane&31)].  key = (|b'|^2 - 2 a'.b') * 128 + local tile index
-            const int nbt = lds_norm[buf * 128 + r] * 128 + (blk * 4 + tile);
+            // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
+            // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
+            int nbt = lds_norm[buf * 128 + r] * 128 + (blk * 4 + tile);
+            asm volatile("" : "+v"(nbt));       // one value per tile: keeps hipcc from re-associating it into every key (lshl + add3)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = nbt - acc[i] * 256;
-                const int mx = best1[i] > key ? best1[i] : key;
-                best2[i] = best2[i] < mx ? best2[i] : mx;
+                const int key = (int)(((unsigned)acc[i] << 8) + (unsigned)nbt);
+                const int lo = best1[i] < best2[i] ? best1[i] : best2[i], hi = best1[i] < best2[i] ? best2[i] : best1[i];
+                const int t = hi < key ? hi : key;
+                best2[i] = lo > t ? lo : t;                                  // max(min(a,b), min(max(a,b), c)) = med3
                 best1[i] = best1[i] < key ? best1[i] : key;
             }
         }
@@ -213,27 +215,49 @@ __global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict
         __syncthreads();
     }
 
-    // widen to global 64-bit keys and merge across the 32 lanes that share the same query rows
+    // Merge across the 32 lanes that share a query row, through LDS (the staging buffers are free after the last
+    // barrier): every lane parks its 16 (best1, best2) pairs, then lane L scans half of row L>>1's 32 parked pairs
+    // in ascending lane order with 32-bit compares -- (key, lane) ordering IS (distance, train index) ordering, and a
+    // strict < keeps the lower lane on ties -- and only the two winners are widened to 64-bit global keys.
+    // (The previous 5-level xor-shuffle merge on 64-bit keys was ~2000 instructions per wave, a third of the kernel.)
+    {
+        int2* wk = (int2*)lds + wave * (32 * 33);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = q0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-        const int qn = pd.qn[row];
-        long long k1 = KEY_INVALID, k2 = KEY_INVALID;
-        if (best1[i] != INT_MAX) {
-            const int e = best1[i] >> 7, tl = best1[i] & 127;
-            k1 = ((long long)(e + qn) << 32) | (unsigned int)(t_begin + tl * 32 + l31);
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+            wk[row * 33 + l31] = make_int2(best1[i], best2[i]);
         }
-        if (best2[i] != INT_MAX) {
-            const int e = best2[i] >> 7, tl = best2[i] & 127;
-            k2 = ((long long)(e + qn) << 32) | (unsigned int)(t_begin + tl * 32 + l31);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int row = lane >> 1, side = lane & 1;
+        int m1 = INT_MAX, m2 = INT_MAX, i1 = 0, i2 = 0;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const long long o1 = shfl_xor_ll(k1, off), o2 = shfl_xor_ll(k2, off);
-            merge2(k1, k2, o1, o2);
+        for (int j = 0; j < 16; ++j) {
+            const int l = side * 16 + j;
+            const int2 v = wk[row * 33 + l];
+            const bool c1 = v.x < m1, c2 = v.x < m2;
+            m2 = c1 ? m1 : (c2 ? v.x : m2); i2 = c1 ? i1 : (c2 ? l : i2);
+            m1 = c1 ? v.x : m1;             i1 = c1 ? l : i1;
+            const bool c3 = v.y < m2;        // v.y >= v.x: it can only displace the runner-up
+            m2 = c3 ? v.y : m2;             i2 = c3 ? l : i2;
         }
-        if (l31 == 0) {
-            long long* o = part + 2 * (pd.part_off + (long long)row * pd.nchunks + chunk);
+        // fold the odd lane (upper 16 source lanes) into the even one; ties stay with the even lane's lower source lanes
+        const int o1 = __shfl_xor(m1, 1), oi1 = __shfl_xor(i1, 1), o2 = __shfl_xor(m2, 1), oi2 = __shfl_xor(i2, 1);
+        {
+            const bool c1 = o1 < m1, c2 = o1 < m2;
+            m2 = c1 ? m1 : (c2 ? o1 : m2); i2 = c1 ? i1 : (c2 ? oi1 : i2);
+            m1 = c1 ? o1 : m1;             i1 = c1 ? oi1 : i1;
+            const bool c3 = o2 < m2;
+            m2 = c3 ? o2 : m2;             i2 = c3 ? oi2 : i2;
+        }
+        if (side == 0) {
+            const int qrow = q0 + row;
+            const int qn = pd.qn[qrow];
+            long long k1 = KEY_INVALID, k2 = KEY_INVALID;
+            if (m1 != INT_MAX) k1 = ((long long)((m1 >> 7) + qn) << 32) | (unsigned int)(t_begin + (m1 & 127) * 32 + i1);
+            if (m2 != INT_MAX) k2 = ((long long)((m2 >> 7) + qn) << 32) | (unsigned int)(t_begin + (m2 & 127) * 32 + i2);
+            long long* o = part + 2 * (pd.part_off + (long long)qrow * pd.nchunks + chunk);
             o[0] = k1; o[1] = k2;
         }
     }
@@ -725,11 +749,11 @@ static int descset_prepare_l2(sfmhip_ctx* ctx, sfmhip_descset* s)
     const bool mfma_ok = s->dim_pad <= 128;    // d^2 <= 128*255^2 < 2^23 keeps the packed keys exact
     if (!mfma_ok) { s->exact_u8 = 0; return SFMHIP_OK; }
     SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_i8, (size_t)s->rows_pad * s->dim_pad));
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_norm, (size_t)s->rows_pad * sizeof(int32_t)));
+    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_norm, 2 * (size_t)s->rows_pad * sizeof(int32_t)));
     SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_flag, sizeof(int)));
     SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
     const int waves_per_block = 4;
-    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block)), dim3(64 * waves_per_block), 0, ctx->stream,
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block * (256 / s->dim_pad))), dim3(64 * waves_per_block), 0, ctx->stream,
                        s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
     SFM_HIP_TRY(ctx, hipGetLastError());
     int flag = 0;
@@ -837,7 +861,7 @@ int sfmhip_descset_refresh(sfmhip_descset* s)
     sfmhip_ctx* ctx = s->ctx;
     if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) return SFMHIP_OK;
     SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, 4)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, 4 * (256 / s->dim_pad))), dim3(256), 0, ctx->stream,
                        s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
@@ -862,7 +886,7 @@ int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
     void* d_tbl = nullptr;
     int rc = sfm_scratch2(ctx, tbl.size() * sizeof(PrepDesc), &d_tbl); if (rc) return rc;
     SFM_HIP_TRY(ctx, hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(prep_l2_batched_kernel, dim3(ceil_div(max_pad, 4), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepDesc*)d_tbl);
+    hipLaunchKernelGGL(prep_l2_batched_kernel, dim3(ceil_div(max_pad, 8), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepDesc*)d_tbl);   // >= 2 rows per wave
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
 }
@@ -924,7 +948,7 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
         memset(&d, 0, sizeof d);
         d.nq = q->rows; d.nt = t->rows; d.nq_pad = q->rows_pad; d.nt_pad = t->rows_pad; d.dim = dim;
         if (P.path == 3) { d.q = q->d_u32; d.t = t->d_u32; }
-        else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
+        else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm + t->rows_pad; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
         const int tblocks = d.nt_pad / 128;
         int nch = (int)((target_wgs + qblocks_total - 1) / (qblocks_total > 0 ? qblocks_total : 1));
         if (P.path == 1) nch = 1 > nch ? 1 : (nch > 8 ? 8 : nch);
