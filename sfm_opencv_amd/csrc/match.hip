@@ -16,7 +16,9 @@
 #pragma clang fp contract(off)
 #include <cfloat>
 #include <climits>
+#include <type_traits>
 
+#define KNN_BLOCK_ROWS 256     // train rows per staged block of knn2_i8_kernel; descriptor sets are padded to it
 #define PAD_NORM 8388607      // 2^23-1: larger than any real partial key, never selected
 #define KEY_INVALID 0x7fffffffffffffffLL
 #define RESCORE_D2 4194304    // 2^22: below this, distinct integers have distinct float32 square roots
@@ -130,23 +132,31 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int off)
 // Partial output: for each (query row, chunk): two 64-bit keys (d2 << 32 | train index), ascending.
 // ------------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part)
+__global__ __launch_bounds__(256, 2) void knn2_i8_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part)
 {
     constexpr int DP = 32 * KS;          // bytes per row
     constexpr int CH = DP / 16;          // 16-byte chunks per row
-    constexpr int PASSES = (128 * CH) / 256;
-    constexpr int STAGE_BYTES = 2 * 128 * DP + 2 * 128 * 4, MERGE_BYTES = 4 * 32 * 33 * 8;
+    constexpr int TROWS = KNN_BLOCK_ROWS, TILES = TROWS / 32;     // train rows staged per barrier
+    constexpr int PASSES = (TROWS * CH) / 256;
+    constexpr int BUF_BYTES = TROWS * DP, NORM_OFF = 2 * BUF_BYTES;
+    constexpr int STAGE_BYTES = 2 * BUF_BYTES + 2 * TROWS * 4, MERGE_BYTES = 4 * 32 * 33 * 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
     const PairDesc pd = pairs[blockIdx.z];
     const int qb = blockIdx.x, chunk = blockIdx.y;
     if (qb * 128 >= pd.nq_pad || chunk >= pd.nchunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int8_t* Q = (const int8_t*)pd.q;
-    const int8_t* T = (const int8_t*)pd.t;
+    // pointers that come out of the PairDesc table are generic to the compiler: without the address-space casts the
+    // train prefetch becomes flat_load, which also counts in lgkmcnt -- every LDS wait then waits for HBM as well
+    typedef const int8_t __attribute__((address_space(1)))* gi8;
+    typedef const int32_t __attribute__((address_space(1)))* gi32;
+    typedef const v4i __attribute__((address_space(1)))* gv4;
+    const gi8 Q = (gi8)(uintptr_t)pd.q;
+    const gi8 T = (gi8)(uintptr_t)pd.t;
+    const gi32 TN = (gi32)(uintptr_t)pd.tn;
     const int t_begin = chunk * pd.chunk_rows;
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt_pad) t_end = pd.nt_pad;
-    const int nblocks = (t_end - t_begin) / 128;
+    const int nblocks = (t_end - t_begin) / TROWS;
     const int q0 = qb * 128 + wave * 32;
 
     // stationary operand: 32 query rows per wave, lane holds row l31, k bytes [32 ks + 16 half, +16), COMPLEMENTED:
@@ -156,62 +166,104 @@ __global__ __launch_bounds__(256) void knn2_i8_kernel(const PairDesc* __restrict
     // neutral: padded query bytes become -1 but meet zero train bytes.
     v4i afrag[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        afrag[ks] = ~*(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
+    for (int ks = 0; ks < KS; ++ks) {
+        afrag[ks] = ~*(gv4)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
+        asm volatile("" : "+v"(afrag[ks]));      // opaque: hipcc otherwise re-derives the complement inside the loop
+    }
 
     int best1[16], best2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { best1[i] = INT_MAX; best2[i] = INT_MAX; }
 
-    int* lds_norm = (int*)(lds + 2 * 128 * DP);
+    // Everything the loop addresses is a per-thread constant plus a compile-time offset (the block loop is unrolled
+    // by two so the LDS buffer is static): the VALU is the busiest unit of this kernel (PMC: SQ_ACTIVE_INST_VALU 74 %
+    // of the wall time), so the loop spends it on the top-2 epilogue only.
+    //   staging: thread -> 16-byte chunk cid = p*256 + tid of the 128 x DP block: global offset cid*16, LDS slot swizzled
+    //   operand reads: row tile*32 + l31, chunk (2 ks + half) ^ ((row >> 1) & (CH-1)); (row >> 1) & 7 does not depend on tile
+    // (chunk cid = p*256 + tid sits at global byte cid*16 and in row r = cid / CH; (r >> 1) & (CH-1) does not depend on p
+    //  when 256 / CH rows per pass is a multiple of 2*CH, so pass p is a compile-time offset on both sides)
+    static_assert((256 / CH) % (2 * CH) == 0 || PASSES == 1, "staging swizzle must repeat per pass");
+    int rd_off[KS];
+    const int st_goff = tid * 16;
+    const int st_loff = (tid / CH) * DP + 16 * ((tid % CH) ^ (((tid / CH) >> 1) & (CH - 1)));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) rd_off[ks] = l31 * DP + 16 * ((2 * ks + half) ^ ((l31 >> 1) & (CH - 1)));
+    const int nrm_off = NORM_OFF + 4 * l31;
+
     v4i stage[PASSES];
     int stage_norm = 0;
     auto g_load = [&](int blk) {
+        const gi8 blk_base = T + (size_t)(t_begin + blk * TROWS) * DP;        // wave-uniform
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
-            stage[p] = *(const v4i*)(T + (size_t)(t_begin + blk * 128 + r) * DP + 16 * c);
-        }
-        if (tid < 128) stage_norm = pd.tn[t_begin + blk * 128 + tid];
+        for (int p = 0; p < PASSES; ++p) stage[p] = *(gv4)(blk_base + p * 4096 + st_goff);
+        // the train-side key term, complete: ((|b|^2 + 2 sum b) << 7) + first tile slot of the block; tile t adds t
+        if (tid < TROWS) stage_norm = TN[t_begin + blk * TROWS + tid] * 128 + blk * TILES + (tid >> 5);
     };
-    auto l_store = [&](int buf) {
+    auto l_store = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
-            *(v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
-        }
-        if (tid < 128) lds_norm[buf * 128 + tid] = stage_norm;
+        for (int p = 0; p < PASSES; ++p) *(v4i*)(lds + st_loff + (buf * BUF_BYTES + p * (256 / CH) * DP)) = stage[p];
+        if (tid < TROWS) *(int*)(lds + NORM_OFF + buf * (4 * TROWS) + 4 * tid) = stage_norm;
     };
-
-    if (nblocks > 0) { g_load(0); l_store(0); }
-    __syncthreads();
-    for (int blk = 0; blk < nblocks; ++blk) {
-        const int buf = blk & 1;
-        if (blk + 1 < nblocks) g_load(blk + 1);
+    // one block of TROWS trains out of LDS buffer `buf`
+    auto compute = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        // Train fragments are requested one tile ahead of their MFMAs (8 live fragment registers sets instead of 16:
+        // 3 waves per SIMD instead of 2).  Tile t+1's MFMAs are interleaved with tile t's epilogue in fixed chunks
+        // (1 MFMA + 16/KS accumulators' worth of epilogue), fenced so the compiler keeps the order: the matrix pipe
+        // runs under the VALU work inside the wave.
+        v4i bfc[KS], bfn[KS];
 #pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            const int r = tile * 32 + l31;
-            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) bfc[ks] = *(const v4i*)(lds + rd_off[ks] + (buf * BUF_BYTES));
+        int nb_cur = 0, nb_next = *(const int*)(lds + nrm_off + (buf * (4 * TROWS)));
+        v16i acc_old = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int tile = 0; tile < TILES + 1; ++tile) {
+            nb_cur = nb_next;                     // tile - 1's key term while tile's MFMAs run
+            if (tile < TILES - 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bfn[ks] = *(const v4i*)(lds + rd_off[ks] + (buf * BUF_BYTES + (tile + 1) * 32 * DP));
+            }
+            if (tile < TILES) nb_next = *(const int*)(lds + nrm_off + (buf * (4 * TROWS) + tile * 128));
+            v16i acc_new = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int c = 2 * ks + half;
-                const v4i b = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], b, acc, 0, 0, 0);
-            }
-            // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
-            // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
-            int nbt = lds_norm[buf * 128 + r] * 128 + (blk * 4 + tile);
-            asm volatile("" : "+v"(nbt));       // one value per tile: keeps hipcc from re-associating it into every key (lshl + add3)
+                if (tile < TILES) acc_new = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfc[ks], acc_new, 0, 0, 0);
+                if (tile > 0) {
+                    // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
+                    // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
+                    const int nbt = nb_cur;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = (int)(((unsigned)acc[i] << 8) + (unsigned)nbt);
-                const int lo = best1[i] < best2[i] ? best1[i] : best2[i], hi = best1[i] < best2[i] ? best2[i] : best1[i];
-                const int t = hi < key ? hi : key;
-                best2[i] = lo > t ? lo : t;                                  // max(min(a,b), min(max(a,b), c)) = med3
-                best1[i] = best1[i] < key ? best1[i] : key;
+                    for (int i = (16 / KS) * ks; i < (16 / KS) * (ks + 1); ++i) {
+                        const int key = (int)(((unsigned)acc_old[i] << 8) + (unsigned)nbt);
+                        const int lo = best1[i] < best2[i] ? best1[i] : best2[i], hi = best1[i] < best2[i] ? best2[i] : best1[i];
+                        const int t = hi < key ? hi : key;
+                        best2[i] = lo > t ? lo : t;                                  // max(min(a,b), min(max(a,b), c)) = med3
+                        best1[i] = best1[i] < key ? best1[i] : key;
+                        asm volatile("" : "+v"(best1[i]), "+v"(best2[i]));          // pin here: LLVM otherwise sinks the whole epilogue below the barrier
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            acc_old = acc_new;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bfc[ks] = bfn[ks];
         }
-        if (blk + 1 < nblocks) l_store(buf ^ 1);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+
+    if (nblocks > 0) { g_load(0); l_store(B0{}); }
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; blk += 2) {
+        if (blk + 1 < nblocks) g_load(blk + 1);
+        compute(B0{});
+        if (blk + 1 < nblocks) l_store(B1{});
+        __syncthreads();
+        if (blk + 1 >= nblocks) break;
+        if (blk + 2 < nblocks) g_load(blk + 2);
+        compute(B1{});
+        if (blk + 2 < nblocks) l_store(B0{});
         __syncthreads();
     }
 
@@ -738,7 +790,7 @@ static int descset_alloc_common(sfmhip_ctx* ctx, int kind, int rows, int dim, sf
 {
     sfmhip_descset* s = new sfmhip_descset();
     s->ctx = ctx; s->kind = kind; s->rows = rows; s->dim = dim;
-    s->rows_pad = round_up(rows > 0 ? rows : 1, 128);
+    s->rows_pad = round_up(rows > 0 ? rows : 1, KNN_BLOCK_ROWS);
     *out = s;
     return SFMHIP_OK;
 }
@@ -949,15 +1001,16 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
         d.nq = q->rows; d.nt = t->rows; d.nq_pad = q->rows_pad; d.nt_pad = t->rows_pad; d.dim = dim;
         if (P.path == 3) { d.q = q->d_u32; d.t = t->d_u32; }
         else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm + t->rows_pad; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
-        const int tblocks = d.nt_pad / 128;
+        const int brows = (P.path == 2) ? KNN_BLOCK_ROWS : 128;               // rows per staged block of the kernel that runs
+        const int tblocks = d.nt_pad / brows, max_cb = 4096 / brows;          // <= 4096 train rows per chunk (7-bit tile index)
         int nch = (int)((target_wgs + qblocks_total - 1) / (qblocks_total > 0 ? qblocks_total : 1));
         if (P.path == 1) nch = 1 > nch ? 1 : (nch > 8 ? 8 : nch);
         if (nch < 1) nch = 1;
         if (nch > tblocks) nch = tblocks;
-        int cb = ceil_div(tblocks, nch);
-        if (cb > 32) cb = 32;                       // <= 4096 train rows per chunk
+        if (nch < ceil_div(tblocks, max_cb)) nch = ceil_div(tblocks, max_cb);
+        const int cb = ceil_div(tblocks, nch);      // balanced chunks
         nch = ceil_div(tblocks, cb);
-        d.nchunks = nch; d.chunk_rows = cb * 128;
+        d.nchunks = nch; d.chunk_rows = cb * brows;
         d.part_off = P.part_entries; P.part_entries += (long long)d.nq_pad * nch;
         d.out_off = P.out_rows; P.out_rows += d.nq;
         d.list_off = P.list_entries; P.list_entries += d.nq > 0 ? d.nq : 1;
