@@ -1,9 +1,9 @@
-"""Subprocess A/B of kNN kernel knock-outs (SFMHIP_EXP_KNN is read once per process)."""
+"""Repeatability check of the matching pass: runs bench.py's matching region a few times in fresh processes."""
 import os, sys, json, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for mode in sys.argv[1:] or ["0", "1", "3"]:
-    env = dict(os.environ, SFMHIP_EXP_KNN=mode)
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-gemm", "--steps", "4", "--warmup", "1"],
-                         env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+                         capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
-    print("mode", mode, "pass ms %.3f  knn+merge+tail ms %.3f" % (d["matched_pairs_per_sec"]["ms_per_pass"], d["roofline_knn"]["ms_per_pass_rank0"]), flush=True)
+    print("rep", rep, "pass ms %.3f  kNN kernel ms %.3f  merge+rescore ms %.3f  frac %.3f" % (
+        d["matched_pairs_per_sec"]["ms_per_pass"], d["roofline"]["avg_launch_ms"], d["roofline"]["merge_rescore_ms"], d["roofline"]["frac"]), flush=True)

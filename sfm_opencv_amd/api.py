@@ -84,6 +84,16 @@ class Context:
     def synchronize(self):
         self._check(self.lib.sfmhip_synchronize(self.h))
 
+    def set_kernel_timing(self, enable=True):
+        """bracket every kNN launch sequence with HIP events (sfmhip_set_kernel_timing)"""
+        self._check(self.lib.sfmhip_set_kernel_timing(self.h, 1 if enable else 0))
+
+    def match_kernel_ms(self):
+        """[kNN kernel ms, merge + re-score ms, calls averaged, 0] since the last query (synchronises)"""
+        out = (C.c_double * 4)()
+        self._check(self.lib.sfmhip_match_kernel_ms(self.h, out))
+        return list(out)
+
     def close(self):
         if self.h:
             self.lib.sfmhip_destroy(self.h)

@@ -20,6 +20,12 @@ struct sfmhip_ctx {
     void*  scratch2 = nullptr;
     size_t scratch2_bytes = 0;
     int    num_cus = 256;
+    // optional per-kernel timing of the matching path (sfmhip_set_kernel_timing): event triples
+    // [before kNN kernel, after it, after merge / re-score] for up to TIMING_SLOTS calls since the last query
+    static constexpr int TIMING_SLOTS = 64;
+    bool   timing = false;
+    int    timing_used = 0;
+    hipEvent_t tev[TIMING_SLOTS][3] = {};
 };
 
 #define SFM_HIP_TRY(ctx, expr)                                                                   \

@@ -31,8 +31,38 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    for (auto& t : ctx->tev) for (auto& e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+int sfmhip_set_kernel_timing(sfmhip_ctx* ctx, int enable)
+{
+    if (!ctx) return SFMHIP_E_ARG;
+    if (enable) {
+        for (auto& t : ctx->tev) for (auto& e : t) if (!e) SFM_HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    ctx->timing = enable != 0;
+    ctx->timing_used = 0;
+    return SFMHIP_OK;
+}
+
+int sfmhip_match_kernel_ms(sfmhip_ctx* ctx, double out_ms[4])
+{
+    if (!ctx || !out_ms) return SFMHIP_E_ARG;
+    out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.0;
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = ctx->timing_used;
+    for (int i = 0; i < n; ++i) {
+        float a = 0.0f, b = 0.0f;
+        SFM_HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->tev[i][0], ctx->tev[i][1]));
+        SFM_HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->tev[i][1], ctx->tev[i][2]));
+        out_ms[0] += a; out_ms[1] += b;
+    }
+    if (n > 0) { out_ms[0] /= n; out_ms[1] /= n; }
+    out_ms[2] = n;
+    ctx->timing_used = 0;
+    return SFMHIP_OK;
 }
 
 int sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream)

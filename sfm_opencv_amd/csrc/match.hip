@@ -1062,6 +1062,8 @@ static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& 
 {
     if (P.max_nq == 0) return SFMHIP_OK;
     const dim3 mgrid(ceil_div(P.max_nq, 256), n_pairs);
+    hipEvent_t* tev = (ctx->timing && ctx->timing_used < sfmhip_ctx::TIMING_SLOTS) ? ctx->tev[ctx->timing_used++] : nullptr;
+    if (tev) (void)hipEventRecord(tev[0], ctx->stream);
     if (P.path == 2) {
         const dim3 grid(P.max_qpad / 128, P.max_chunks, n_pairs);
         switch (P.ks) {
@@ -1071,18 +1073,22 @@ static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& 
             default: ctx->last_error = "int8 path: dim > 128"; return SFMHIP_E_ARG;
         }
         SFM_HIP_TRY(ctx, hipGetLastError());
+        if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<0>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, W.d_list, W.d_count, 0);
         // rows whose float distances may tie although the integers differ: exact re-score (normally none)
         if (P.aligned) launch_exact<true>(ctx, P, W, n_pairs, true); else launch_exact<false>(ctx, P, W, n_pairs, true);
         hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, W.d_list, W.d_count, 1);
     } else if (P.path == 1) {
         if (P.aligned) launch_exact<true>(ctx, P, W, n_pairs, false); else launch_exact<false>(ctx, P, W, n_pairs, false);
+        if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
     } else {
         const dim3 grid(ceil_div(P.max_qpad, 256), P.max_chunks, n_pairs);
         hipLaunchKernelGGL(knn2_hamming2_kernel, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part);
+        if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<2>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
     }
+    if (tev) (void)hipEventRecord(tev[2], ctx->stream);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
 }
