@@ -128,6 +128,28 @@ __global__ __launch_bounds__(1024) void chol_solve_kernel(const double* __restri
     for (int i = tid; i < n; i += 1024) y[i] = b[i];
 }
 
+// Multi-rank message: only the 32x32 blocks of the lower triangle that the Schur complement can populate (camera
+// adjacency + intrinsics row, diagonal blocks whole) plus the tail [rhs | diagU | graw | scalars] travel through the
+// all-reduce hook -- at C4 1.4 MB instead of the 12 MB dense square.  dir 0: S -> message, 1: message -> S.
+__global__ __launch_bounds__(256) void ba_pack_kernel(double* __restrict__ S, int ld, const int* __restrict__ sblk, int n_sblk,
+                                                      double* __restrict__ tail, size_t tail_count, double* __restrict__ msg, int dir)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b < n_sblk) {
+        const int bi = sblk[2 * b], bj = sblk[2 * b + 1];
+        for (int e = tid; e < NB * NB; e += 256) {
+            double* g = S + (size_t)(bi * NB + (e >> 5)) * ld + bj * NB + (e & 31);
+            double* m = msg + (size_t)b * NB * NB + e;
+            if (dir == 0) *m = *g; else *g = *m;
+        }
+    } else {
+        const size_t base = (size_t)n_sblk * NB * NB;
+        for (size_t e = (size_t)(b - n_sblk) * 256 + tid; e < tail_count; e += (size_t)(gridDim.x - n_sblk) * 256) {
+            if (dir == 0) msg[base + e] = tail[e]; else tail[e] = msg[base + e];
+        }
+    }
+}
+
 __global__ void fill_kernel(double* __restrict__ p, size_t n, double v)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,6 +181,7 @@ struct sfmhip_ba {
     std::vector<int> pt_slot;                 // caller's point index -> slot in the HBM arrays (points sorted by camera set)
     int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
     double* d_topbuf = nullptr; size_t topbuf_count = 0;
+    int* d_sblk = nullptr; int n_sblk = 0; double* d_pack = nullptr; size_t pack_cap = 0;     // packed all-reduce message
     double* d_ouv = nullptr;
     // work
     double *d_scale_c = nullptr, *d_scale_p = nullptr, *d_Vinv = nullptr, *d_bp = nullptr, *d_WK = nullptr, *d_colsq_p = nullptr;
@@ -245,7 +268,17 @@ static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp, bool timed 
     }
     if (timed) (void)hipEventRecord(h->ev[7], st);
     SFM_HIP_TRY(ctx, hipGetLastError());
-    int rc = call_allreduce(h, h->d_msg, h->msg_count); if (rc) return rc;
+    if (h->ar_fn) {
+        const size_t np2 = (size_t)h->npad * h->npad, tail = h->msg_count - np2, count = (size_t)h->n_sblk * NB * NB + tail;
+        const int tail_blocks = (int)std::min<size_t>((tail + 255) / 256, 64);
+        hipLaunchKernelGGL(ba_pack_kernel, dim3(h->n_sblk + tail_blocks), dim3(256), 0, st, h->d_msg, h->npad, h->d_sblk, h->n_sblk,
+                           h->d_msg + np2, tail, h->d_pack, 0);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        int rc = call_allreduce(h, h->d_pack, count); if (rc) return rc;
+        hipLaunchKernelGGL(ba_pack_kernel, dim3(h->n_sblk + tail_blocks), dim3(256), 0, st, h->d_msg, h->npad, h->d_sblk, h->n_sblk,
+                           h->d_msg + np2, tail, h->d_pack, 1);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+    }
     if (damp) { hipLaunchKernelGGL(ba_damp_kernel, dim3(1), dim3(256), 0, st, P); SFM_HIP_TRY(ctx, hipGetLastError()); }
     return SFMHIP_OK;
 }
@@ -396,6 +429,8 @@ static int build_solver_plan(sfmhip_ba* h)
         if (!h->fixK) mark(h->koff, h->koff, 4, 4);
         for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c)
             if (adj[(size_t)a * ncf + c] != 0.0) mark(h->cam_pos[a + f0], h->cam_pos[c + f0], 6, 6);
+        std::vector<int> sblk;                      // blocks S can populate (before fill): what a multi-rank all-reduce carries
+        for (int i = 0; i < nb; ++i) for (int j = 0; j <= i; ++j) if (Pm[(size_t)i * nb + j]) { sblk.push_back(i); sblk.push_back(j); }
         std::vector<int> start(nb + 1, 0), rows;
         int maxR = 0; bool independent = true;
         for (int k = 0; k < nb; ++k) {
@@ -432,8 +467,15 @@ static int build_solver_plan(sfmhip_ba* h)
                 }
             }
         } else if (P > 1) continue;                                   // the dense path uses the natural single-segment layout
-        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;
+        h->n_sblk = (int)sblk.size() / 2;
+        {
+            int rc = dalloc(h, &h->d_sblk, sblk.size()); if (rc) return rc;
+            SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_sblk, sblk.data(), sblk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            const size_t need = (size_t)h->n_sblk * NB * NB + (h->msg_count - (size_t)h->npad * h->npad);
+            if (need > h->pack_cap) { rc = dalloc(h, &h->d_pack, need); if (rc) return rc; h->pack_cap = need; }
+        }
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return SFMHIP_OK;
     }
     ctx->last_error = "internal: no solver layout";
@@ -786,7 +828,8 @@ int sfmhip_ba_reduced_system(sfmhip_ba* h, double radius, double* S, double* rhs
             const int pi = h->pos_param[i];
             if (pi < 0) continue;
             if (rhs) rhs[pi] = full[np2 + i];
-            if (S) for (int j = 0; j < h->npad; ++j) { const int pj = h->pos_param[j]; if (pj >= 0) S[(size_t)pi * h->n + pj] = full[(size_t)i * h->npad + j]; }
+            // the lower triangle is the authoritative copy (the only one a multi-rank all-reduce carries)
+            if (S) for (int j = 0; j < h->npad; ++j) { const int pj = h->pos_param[j]; if (pj >= 0) S[(size_t)pi * h->n + pj] = full[(size_t)std::max(i, j) * h->npad + std::min(i, j)]; }
         }
     }
     if (cost) SFM_HIP_TRY(ctx, hipMemcpy(cost, h->d_msg + np2 + 3 * (size_t)h->npad, sizeof(double), hipMemcpyDeviceToHost));

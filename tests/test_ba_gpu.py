@@ -137,6 +137,65 @@ def test_allreduce_hook_identity_and_failure(ctx):
         bad.iterate(1)
 
 
+def test_two_point_shards_on_one_gpu_match_unsharded(ctx):
+    """SURVEY 8e on a single card: two contexts, each with half of the points, driven by two threads whose
+    all-reduce hook sums the two libraries' packed messages -- the N>1 data path (packed non-zero blocks through the
+    hook, replicated solve, sharded back-substitution) against the unsharded solve."""
+    import threading
+    import torch
+    from sfm_opencv_amd import dist as sdist
+    sc = synth.ba_scene(24, 4000)
+    ref = ctx.ba_create(*_args(sc)); sr = ref.iterate(5); Kr, extr, ptsr = ref.params()
+    world = 2
+    ctxs = [api.Context(0, use_torch_stream=False) for _ in range(world)]
+    probs, ids = [], []
+    for r in range(world):
+        pts_l, oc, op, uv, pid = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], r, world)
+        probs.append(ctxs[r].ba_create(sc["K0"], sc["ext0"], pts_l, oc, op, uv)); ids.append(pid)
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    counts = [[] for _ in range(world)]
+
+    def make_hook(r):
+        def hook(ptr, count, stream):
+            ctxs[r].synchronize()                                   # this rank's message is complete
+            slots[r] = torch.as_tensor(sdist._CudaView(ptr, count), device="cuda")
+            counts[r].append(count)
+            bar.wait()
+            if r == 0:
+                total = slots[0] + slots[1]
+                slots[0].copy_(total); slots[1].copy_(total)
+                torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        return hook
+
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            probs[r].set_allreduce(make_hook(r), r, world)
+            out[r] = probs[r].iterate(5)
+        except Exception as e:                                      # pragma: no cover
+            errs.append(e); bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(120)
+    assert not errs and all(o is not None for o in out)
+    assert counts[0] == counts[1] and len(counts[0]) >= 10
+    n_red = 6 * (sc["n_cam"] - 1) + 4
+    assert max(counts[0]) < n_red * n_red                           # packed: fewer doubles than the dense square
+    for r in range(world):
+        assert out[r]["iterations"] == sr["iterations"] and out[r]["successful_steps"] == sr["successful_steps"]
+        assert abs(out[r]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        K, ext, pts = probs[r].params()
+        assert np.abs(ext - extr).max() <= 1e-9 and np.abs(K - Kr).max() <= 1e-9 * np.abs(Kr).max()
+        assert np.abs(pts - ptsr[ids[r]]).max() <= 1e-9
+    for pb in probs: pb.close()
+    for c in ctxs: c.close()
+
+
 def test_bundle_adjustment_wrapper_in_place(ctx, capsys):
     sc = synth.ba_scene(6, 200, outlier_frac=0.0)
     kps, ids = [], []
