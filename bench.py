@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--config", default="C4", choices=["C3", "C4", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: the box's cores, at most 16)")
     args = ap.parse_args()
 
     import torch
@@ -155,7 +156,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and rank == 0:
         import oracle as orc
-        cores = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
+        cores = args.cpu_threads if args.cpu_threads > 0 else min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
         orc.set_num_threads(cores)
         n_it_cpu = 3
         tc = time.perf_counter()
