@@ -21,6 +21,11 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, world, local = env_rank_world()
+    # rehearsal knobs (several ranks sharing one card, where RCCL refuses duplicate devices):
+    # SFM_DIST_BACKEND=gloo, SFM_LOCAL_DEVICE=0
+    backend = backend or os.environ.get("SFM_DIST_BACKEND") or None
+    if "SFM_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["SFM_LOCAL_DEVICE"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
