@@ -1,0 +1,124 @@
+"""Parity at BASELINE.json's full sizes (C4 per-pair 5000 x 5000 x 128, the 10k x 10k roofline case, the 200-camera /
+300k-point BA scene) through size-independent properties plus oracle spot checks on slices the oracle finishes in
+seconds.  Everything goes through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from sfm_opencv_amd import synth, api
+from sfm_opencv_amd import dist as sdist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c4_pair_self_match_permutation_and_oracle_slice(ctx):
+    d = synth.sift_descriptor_chain(2, 5000, seed=4242)
+    a, b = d[0], d[1]
+    # (1) a set matched against itself: every row finds itself at distance 0 first (ties -> lower index: rows are distinct)
+    gi, gd = ctx.knn2_l2(a, a)
+    uniq = np.unique(a, axis=0).shape[0] == a.shape[0]
+    if uniq:
+        assert np.array_equal(gi[:, 0], np.arange(5000)) and not gd[:, 0].any()
+    assert (gd[:, 1] >= gd[:, 0]).all()
+    # (2) permuting the train rows permutes the answer (distances bit-identical) -- rows are distinct, so no tie order issue
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(5000)
+    gi1, gd1 = ctx.knn2_l2(a, b)
+    gi2, gd2 = ctx.knn2_l2(a, b[perm])
+    assert np.array_equal(gd1.view(np.uint32), gd2.view(np.uint32))
+    clean = gd1[:, 0] != gd1[:, 1]                       # a tie between best and runner-up may swap under a permutation
+    assert np.array_equal(perm[gi2[clean]], gi1[clean])
+    # (3) oracle on a slice of the queries against all 5000 trains: bit-exact
+    rows = rng.choice(5000, 300, replace=False)
+    oi, od = orc.knn2_l2(a[rows], b)
+    assert np.array_equal(gi1[rows], oi) and np.array_equal(gd1[rows].view(np.uint32), od.view(np.uint32))
+    # (4) the ratio tail of the full pair equals the host tail applied to the device kNN
+    m = api.match_features(a, b, ctx=ctx)
+    ref = api.ratio_filter(gi1, gd1)
+    assert np.array_equal(m["queryIdx"], ref["queryIdx"]) and np.array_equal(m["trainIdx"], ref["trainIdx"])
+
+
+def test_10k_distance_matrix_properties(ctx):
+    d = synth.sift_descriptor_chain(2, 10000, seed=777)
+    q = torch.from_numpy(d[0]).cuda(); t = torch.from_numpy(d[1]).cuda()
+    qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
+    out = torch.empty((10000, 10000), dtype=torch.float32, device="cuda")
+    out_t = torch.empty((10000, 10000), dtype=torch.float32, device="cuda")
+    ctx.l2_distance_matrix_dev(qs, ts, out)
+    ctx.l2_distance_matrix_dev(ts, qs, out_t)
+    ctx.synchronize()
+    # symmetry: d(q_i, t_j) computed from either side is the same float
+    assert torch.equal(out, out_t.t())
+    # row minima agree with the fused kNN kernel (same integers -> same floats)
+    gi, gd = ctx.knn2_l2(d[0], d[1])
+    mn = out.min(dim=1).values.cpu().numpy()
+    assert np.array_equal(mn.view(np.uint32), gd[:, 0].view(np.uint32))
+    # oracle spot check: 64 random rows, bit-exact
+    rows = np.random.default_rng(1).choice(10000, 64, replace=False)
+    ref = orc.l2_distance_matrix(d[0][rows], d[1])
+    got = out[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_c4_triangulation_round_trip(ctx):
+    s = synth.two_view_scene(200_000, noise_px=0.0)
+    P1 = api.projection_matrix(s["K"], s["R1"], s["T1"]); P2 = api.projection_matrix(s["K"], s["R2"], s["T2"])
+    _, X = ctx.triangulate2(P1, P2, s["xy1"], s["xy2"])
+    # project -> triangulate returns the point: float32 pixels (1/4096 px quantisation at u ~ 2000) over a 1-unit baseline
+    rel = np.linalg.norm(X - s["X"], axis=1) / np.linalg.norm(s["X"], axis=1)
+    assert rel.max() < 2e-3 and np.median(rel) < 5e-5
+    # scaling both pixel sets' homogeneous rows leaves the DLT null vector unchanged: a permutation of the matches permutes X
+    perm = np.random.default_rng(2).permutation(200_000)
+    _, Xp = ctx.triangulate2(P1, P2, s["xy1"][perm], s["xy2"][perm])
+    assert np.array_equal(Xp, X[perm])
+
+
+def test_c4_bundle_adjustment_full_size(ctx):
+    cfg = synth.CONFIGS["C4"]
+    sc = synth.ba_scene(cfg["n_img"], cfg["n_pt"])
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    # (1) one linearisation against the oracle at full size (n = 1198): 1e-9 relative to the largest entry
+    pb = ctx.ba_create(*args)
+    S, rhs, cost = pb.reduced_system(1e4)
+    orc.set_num_threads(16)
+    So, rhso, costo = orc.ba_reduced_system(*args, 1e4)
+    assert abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(rhs - rhso).max() <= 1e-9 * np.abs(rhso).max()
+    # (2) LM trajectory: the cost never increases over accepted steps, and reaches the noise floor of the scene
+    costs = [pb.iterate(1)["final_cost"] for _ in range(12)]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    rmse = np.sqrt(costs[-1] / (2 * sc["n_obs"]))
+    assert rmse < 2.5
+    K, ext, pts = pb.params()
+    # (3) relabelling the points (a permutation of point ids and of the observation list) changes nothing beyond rounding
+    rng = np.random.default_rng(3)
+    pperm = rng.permutation(sc["n_pt"]); inv = np.empty_like(pperm); inv[pperm] = np.arange(sc["n_pt"])
+    operm = rng.permutation(sc["n_obs"])
+    pb2 = ctx.ba_create(sc["K0"], sc["ext0"], sc["pts0"][pperm], sc["obs_cam"][operm], inv[sc["obs_pt"]][operm].astype(np.int32), sc["obs_uv"][operm])
+    s2 = pb2.iterate(12)
+    # (different fp64 summation orders through 12 LM iterations: 1e-7 on the cost, 1e-9 on the cameras; a point's update is
+    #  V_p^-1 (...) with cond(V_p) up to ~1e10 for two-view points at a narrow baseline or with an outlier pixel, so the
+    #  bulk of the points must agree to 1e-9 and the worst-conditioned few to 1e-3)
+    assert abs(s2["final_cost"] - costs[-1]) <= 1e-7 * costs[-1]
+    K2, ext2, pts2 = pb2.params()
+    dp = np.abs(pts2 - pts[pperm]).max(axis=1)
+    q = np.quantile(dp, [0.5, 0.99, 0.999, 1.0])
+    assert np.abs(ext2 - ext).max() <= 1e-9 and np.abs(K2 - K).max() <= 1e-9 * np.abs(K).max()
+    assert q[0] <= 1e-11 and q[1] <= 1e-9 and q[3] <= 1e-3, f"point differences, quantiles 0.5/0.99/0.999/1: {q}"
+    # (4) partial systems over 4 point shards add up to the full one (the multi-GPU contract, radius < 0 form)
+    #     (column scaling off: each shard would otherwise scale by its own column norms)
+    o = ctx.ba_options(jacobi_scaling=0)
+    full = ctx.ba_create(K, ext, pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], opts=o)
+    Sf, rf, cf = full.reduced_system(-1e4)
+    full.close()
+    acc_S = np.zeros_like(Sf); acc_r = np.zeros_like(rf); acc_c = 0.0
+    for r in range(4):
+        pl, oc, op, uv, ids = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], pts, r, 4)
+        sh = ctx.ba_create(K, ext, pl, oc, op, uv, opts=o)
+        Ss, rs, cs = sh.reduced_system(-1e4)
+        acc_S += Ss; acc_r += rs; acc_c += cs
+        sh.close()
+    assert abs(acc_c - cf) <= 1e-11 * cf
+    assert np.abs(acc_S - Sf).max() <= 1e-10 * np.abs(Sf).max() and np.abs(acc_r - rf).max() <= 1e-10 * max(np.abs(rf).max(), 1e-300)
+    pb.close(); pb2.close()
