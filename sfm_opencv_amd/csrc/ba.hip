@@ -197,6 +197,7 @@ struct sfmhip_ba {
     double radius = 0, nu = 2, x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0;
     int iter = 0, nsucc = 0, ninvalid = 0, termination = SFMHIP_BA_NO_CONVERGENCE;
     hipEvent_t ev[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // second stream: the Schur pair kernel runs beside the camera kernel
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
 
@@ -257,16 +258,25 @@ static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp, bool timed 
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
     hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
+    // The camera kernel (one wave per SIMD: 80 fp64 accumulators per thread) and the Schur pair kernel both depend only on
+    // the point kernel and both leave most of the chip's issue slots idle, so they run side by side: the pair kernel on
+    // the auxiliary stream, its partials folded into S (ba_schur_reduce_kernel, the only writer) after the join.
+    if (h->nblk > 0) {
+        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
+        SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        if (timed) (void)hipEventRecord(h->ev[6], h->aux);
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(ceil_div(h->nchunk, 4)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        if (timed) (void)hipEventRecord(h->ev[7], h->aux);
+        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
+    } else if (timed) { (void)hipEventRecord(h->ev[6], st); (void)hipEventRecord(h->ev[7], st); }
     if (timed) (void)hipEventRecord(h->ev[4], st);
-    hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split, h->fixK ? 1 : 2), dim3(256), 0, st, P);     // z = 1: camera-intrinsic sums
     if (timed) (void)hipEventRecord(h->ev[5], st);
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
-    if (timed) (void)hipEventRecord(h->ev[6], st);
     if (h->nblk > 0) {
-        hipLaunchKernelGGL(ba_schur_kernel, dim3(ceil_div(h->nchunk, 4)), dim3(256), 0, st, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
         hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
     }
-    if (timed) (void)hipEventRecord(h->ev[7], st);
     SFM_HIP_TRY(ctx, hipGetLastError());
     if (h->ar_fn) {
         const size_t np2 = (size_t)h->npad * h->npad, tail = h->msg_count - np2, count = (size_t)h->n_sblk * NB * NB + tail;
@@ -637,6 +647,9 @@ void sfmhip_ba_destroy(sfmhip_ba* h)
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -749,6 +762,8 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
 #undef TRY_RC
     if (hipHostMalloc((void**)&h->h_scal, 16 * sizeof(double)) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipHostMalloc"; return SFMHIP_E_HIP; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "auxiliary stream"; return SFMHIP_E_HIP; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "upload failed"; return SFMHIP_E_HIP; }
     *out = h;
     return SFMHIP_OK;

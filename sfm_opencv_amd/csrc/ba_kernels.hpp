@@ -337,9 +337,13 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
 //   [71,77) graw_c = Ec'r
 // ------------------------------------------------------------------------------------------------
 #define CAMACC 80
-__global__ __launch_bounds__(256) void ba_camera_kernel(BADev P)
+// The 77 sums are split over two kinds of workgroups (blockIdx.z): part 0 keeps the camera-camera terms (Scc, rhs_c,
+// diagU_c, graw_c: 39 accumulators), part 1 the camera-intrinsic ones (ScK, UKK, gK: 38).  Both re-derive the
+// linearisation; with all 77 in one thread the kernel needed 324 registers = one wave per SIMD, and PMC showed it
+// 42 % waiting on its gathers with nothing else resident to issue (140 us; the split form: see profiles/README.md).
+template <int PART>
+__device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAMACC])
 {
-    __shared__ double red[4][CAMACC];
     const int c = blockIdx.x, sp_i = blockIdx.y;
     const int co = cam_off(P, c);
     double acc[CAMACC];
@@ -357,13 +361,9 @@ __global__ __launch_bounds__(256) void ba_camera_kernel(BADev P)
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         ObsLin o;
         obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, sc, spp, o);
-        double Vi[6], b[3], WK[12];
+        double Vi[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) b[i] = P.bp[3 * (size_t)p + i];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) WK[i] = P.WK[12 * (size_t)p + i];
         double W[6][3], T[6][3];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -371,44 +371,63 @@ __global__ __launch_bounds__(256) void ba_camera_kernel(BADev P)
             for (int j = 0; j < 3; ++j) W[i][j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
             symv3(Vi, W[i], T[i]);
         }
-        int a = 0;
+        if (PART == 0) {
+            double b[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 3; ++i) b[i] = P.bp[3 * (size_t)p + i];
+            int a = 0;
 #pragma unroll
-            for (int j = 0; j <= i; ++j)
-                acc[a++] += o.Ec[0][i] * o.Ec[0][j] + o.Ec[1][i] * o.Ec[1][j]
-                            - (T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2]);
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+                for (int j = 0; j <= i; ++j)
+                    acc[a++] += o.Ec[0][i] * o.Ec[0][j] + o.Ec[1][i] * o.Ec[1][j]
+                                - (T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[a++] += o.Ec[0][i] * o.EK[0][j] + o.Ec[1][i] * o.EK[1][j]
-                            - (T[i][0] * WK[3 * j] + T[i][1] * WK[3 * j + 1] + T[i][2] * WK[3 * j + 2]);
+            for (int i = 0; i < 6; ++i)
+                acc[45 + i] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1] - (T[i][0] * b[0] + T[i][1] * b[1] + T[i][2] * b[2]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            acc[a++] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1] - (T[i][0] * b[0] + T[i][1] * b[1] + T[i][2] * b[2]);
+            for (int i = 0; i < 6; ++i) acc[65 + i] += o.Ec[0][i] * o.Ec[0][i] + o.Ec[1][i] * o.Ec[1][i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 6; ++i) acc[71 + i] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1];
+        } else {
+            double WK[12];
 #pragma unroll
-            for (int j = 0; j <= i; ++j) acc[a++] += o.EK[0][i] * o.EK[0][j] + o.EK[1][i] * o.EK[1][j];
+            for (int i = 0; i < 12; ++i) WK[i] = P.WK[12 * (size_t)p + i];
+            int a = 21;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[a++] += o.EK[0][i] * o.r[0] + o.EK[1][i] * o.r[1];
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[a++] += o.Ec[0][i] * o.Ec[0][i] + o.Ec[1][i] * o.Ec[1][i];
+                for (int j = 0; j < 4; ++j)
+                    acc[a++] += o.Ec[0][i] * o.EK[0][j] + o.Ec[1][i] * o.EK[1][j]
+                                - (T[i][0] * WK[3 * j] + T[i][1] * WK[3 * j + 1] + T[i][2] * WK[3 * j + 2]);
+            a = 51;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[a++] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) acc[a++] += o.EK[0][i] * o.EK[0][j] + o.EK[1][i] * o.EK[1][j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[61 + i] += o.EK[0][i] * o.r[0] + o.EK[1][i] * o.r[1];
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this part's slots: part 0 -> [0,21) u [45,51) u [65,77), part 1 -> [21,45) u [51,65)
 #pragma unroll
-    for (int i = 0; i < 77; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < CAMACC; ++i) red[wave][i] = acc[i];
-    __syncthreads();
-    if (threadIdx.x < CAMACC) {
-        const int i = threadIdx.x;
-        P.part_cam[((size_t)c * P.cam_split + sp_i) * CAMACC + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    for (int i = 0; i < 77; ++i) {
+        const bool mine = (PART == 0) ? (i < 21 || (i >= 45 && i < 51) || i >= 65) : ((i >= 21 && i < 45) || (i >= 51 && i < 65));
+        if (mine) { acc[i] = wave_sum(acc[i]); if (lane == 0) red[wave][i] = acc[i]; }
     }
+    __syncthreads();
+    if (threadIdx.x < 77) {
+        const int i = threadIdx.x;
+        const bool mine = (PART == 0) ? (i < 21 || (i >= 45 && i < 51) || i >= 65) : ((i >= 21 && i < 45) || (i >= 51 && i < 65));
+        if (mine) P.part_cam[((size_t)c * P.cam_split + sp_i) * CAMACC + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void ba_camera_kernel(BADev P)
+{
+    __shared__ double red[4][CAMACC];
+    if (blockIdx.z == 0) ba_camera_body<0>(P, red); else ba_camera_body<1>(P, red);
 }
 
 // ------------------------------------------------------------------------------------------------
