@@ -85,14 +85,30 @@ __global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl)
     prep_l2_rows(d.src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, d.dst, d.norm, d.flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
-// Hamming: copy rows into 64-byte zero-padded rows (16 dwords)
+// Hamming2: rows into 64-byte zero-padded rows, re-encoded so that one dword carries 32 two-bit cells' LOW bits and
+// another their HIGH bits: with a[0..15] the 16 dwords of a row and M = 0x55555555,
+//     L[i] = (a[2i] & M) | ((a[2i+1] & M) << 1),   H[i] = ((a[2i] >> 1) & M) | (a[2i+1] & ~M),   i = 0..7
+// (cells of a[2i] on the even bit positions, cells of a[2i+1] on the odd ones).  A cell differs iff its low bits or its
+// high bits differ, so NORM_HAMMING2(a, b) = sum_i popcount((La[i]^Lb[i]) | (Ha[i]^Hb[i])): 3 VALU ops per 32 cells
+// (v_xor, v_bitop3, v_bcnt) instead of 5 per 16.  Stored as [L0..L7 | H0..H7].
 __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
-                                    uint8_t* __restrict__ dst, int rows_pad)
+                                    uint32_t* __restrict__ dst, int rows_pad)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)rows_pad * 64) return;
-    const int row = (int)(i >> 6), k = (int)(i & 63);
-    dst[i] = (row < rows && k < nbytes) ? src[(size_t)row * ld + k] : (uint8_t)0;
+    if (i >= (size_t)rows_pad * 8) return;
+    const int row = (int)(i >> 3), k = (int)(i & 7);
+    uint32_t a0 = 0, a1 = 0;
+    if (row < rows) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k0 = 8 * k + b, k1 = 8 * k + 4 + b;
+            if (k0 < nbytes) a0 |= (uint32_t)src[(size_t)row * ld + k0] << (8 * b);
+            if (k1 < nbytes) a1 |= (uint32_t)src[(size_t)row * ld + k1] << (8 * b);
+        }
+    }
+    const uint32_t M = 0x55555555u;
+    dst[(size_t)row * 16 + k] = (a0 & M) | ((a1 & M) << 1);
+    dst[(size_t)row * 16 + 8 + k] = ((a0 >> 1) & M) | (a1 & ~M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,24 +671,50 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
     if ((int)blockIdx.x * 256 >= pd.nq_pad || chunk >= pd.nchunks) return;
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int rrow = row < pd.nq_pad ? row : 0;
-    const uint4* Q = (const uint4*)pd.q;
-    const uint4* T = (const uint4*)pd.t;
-    const uint4 q0 = Q[(size_t)rrow * 4 + 0], q1 = Q[(size_t)rrow * 4 + 1], q2 = Q[(size_t)rrow * 4 + 2], q3 = Q[(size_t)rrow * 4 + 3];
+    // Train rows go through the scalar path: the address is wave-uniform, and a pointer in the constant address space
+    // makes hipcc emit s_load_dwordx16 into SGPRs (a generic pointer out of the PairDesc table became 64-lane flat_load
+    // broadcasts with a full vmcnt(0) wait per row).  Two rows per trip, the next pair requested before this one is used.
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef const u4v __attribute__((address_space(1)))* gu4;
+    typedef const u4v __attribute__((address_space(4)))* cu4;
+    const gu4 Q = (gu4)(uintptr_t)pd.q;
+    const cu4 T = (cu4)(uintptr_t)pd.t;
+    const u4v q0 = Q[(size_t)rrow * 4 + 0], q1 = Q[(size_t)rrow * 4 + 1], q2 = Q[(size_t)rrow * 4 + 2], q3 = Q[(size_t)rrow * 4 + 3];
     const int t_begin = chunk * pd.chunk_rows;
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt) t_end = pd.nt;
     int best1 = INT_MAX, best2 = INT_MAX;
-#define H2(x, y) __popc((((x) ^ (y)) | (((x) ^ (y)) << 1)) & 0xAAAAAAAAu)
-    for (int j = t_begin; j < t_end; ++j) {
-        const uint4 t0 = T[(size_t)j * 4 + 0], t1 = T[(size_t)j * 4 + 1], t2 = T[(size_t)j * 4 + 2], t3 = T[(size_t)j * 4 + 3];
-        int d = H2(q0.x, t0.x) + H2(q0.y, t0.y) + H2(q0.z, t0.z) + H2(q0.w, t0.w)
-              + H2(q1.x, t1.x) + H2(q1.y, t1.y) + H2(q1.z, t1.z) + H2(q1.w, t1.w)
-              + H2(q2.x, t2.x) + H2(q2.y, t2.y) + H2(q2.z, t2.z) + H2(q2.w, t2.w)
-              + H2(q3.x, t3.x) + H2(q3.y, t3.y) + H2(q3.z, t3.z) + H2(q3.w, t3.w);
-        const int key = (d << 22) | (j - t_begin);
-        const int mx = best1 > key ? best1 : key;
-        best2 = best2 < mx ? best2 : mx;
-        best1 = best1 < key ? best1 : key;
+    // rows are [L0..L7 | H0..H7] (prep_hamming_kernel): q0,q1 = low-bit dwords, q2,q3 = high-bit dwords
+#define H2(ql, tl, qh, th) __popc(((ql) ^ (tl)) | ((qh) ^ (th)))
+#define ROW_DIST(t0, t1, t2, t3)                                                                                                   \
+    (H2(q0.x, t0.x, q2.x, t2.x) + H2(q0.y, t0.y, q2.y, t2.y) + H2(q0.z, t0.z, q2.z, t2.z) + H2(q0.w, t0.w, q2.w, t2.w)             \
+   + H2(q1.x, t1.x, q3.x, t3.x) + H2(q1.y, t1.y, q3.y, t3.y) + H2(q1.z, t1.z, q3.z, t3.z) + H2(q1.w, t1.w, q3.w, t3.w))
+#define TOP2(d, jrel)                                                                                                              \
+    do {                                                                                                                           \
+        const int key = ((d) << 22) | (jrel);                                                                                      \
+        const int lo = best1 < best2 ? best1 : best2, hi = best1 < best2 ? best2 : best1;                                          \
+        const int t = hi < key ? hi : key;                                                                                         \
+        best2 = lo > t ? lo : t;                            /* med3(best1, best2, key) */                                          \
+        best1 = best1 < key ? best1 : key;                                                                                         \
+    } while (0)
+    // rows_pad is a multiple of 256 and pad rows are zero: reading one row pair past t_end stays inside the buffer
+    int j = t_begin;
+    u4v a0 = T[(size_t)j * 4 + 0], a1 = T[(size_t)j * 4 + 1], a2 = T[(size_t)j * 4 + 2], a3 = T[(size_t)j * 4 + 3];
+    u4v b0 = T[(size_t)j * 4 + 4], b1 = T[(size_t)j * 4 + 5], b2 = T[(size_t)j * 4 + 6], b3 = T[(size_t)j * 4 + 7];
+    for (; j + 2 <= t_end; j += 2) {
+        const int jn = (j + 2 < pd.nt_pad - 1) ? j + 2 : j;      // next pair (clamped inside the padded buffer)
+        const u4v c0 = T[(size_t)jn * 4 + 0], c1 = T[(size_t)jn * 4 + 1], c2 = T[(size_t)jn * 4 + 2], c3 = T[(size_t)jn * 4 + 3];
+        const u4v e0 = T[(size_t)jn * 4 + 4], e1 = T[(size_t)jn * 4 + 5], e2 = T[(size_t)jn * 4 + 6], e3 = T[(size_t)jn * 4 + 7];
+        const int da = ROW_DIST(a0, a1, a2, a3), db = ROW_DIST(b0, b1, b2, b3);
+        TOP2(da, j - t_begin);
+        TOP2(db, j + 1 - t_begin);
+        a0 = c0; a1 = c1; a2 = c2; a3 = c3; b0 = e0; b1 = e1; b2 = e2; b3 = e3;
     }
+    if (j < t_end) {
+        const int da = ROW_DIST(a0, a1, a2, a3);
+        TOP2(da, j - t_begin);
+    }
+#undef TOP2
+#undef ROW_DIST
 #undef H2
     if (row < pd.nq_pad) {
         long long k1 = KEY_INVALID, k2 = KEY_INVALID;
@@ -855,8 +897,8 @@ static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uin
 {
     SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_u32, (size_t)s->rows_pad * 64));
     const size_t n = (size_t)s->rows_pad * 64;
-    hipLaunchKernelGGL(prep_hamming_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_src, ld, s->rows, s->dim, (uint8_t*)s->d_u32, s->rows_pad);
+    hipLaunchKernelGGL(prep_hamming_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_src, ld, s->rows, s->dim, (uint32_t*)s->d_u32, s->rows_pad);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
 }
