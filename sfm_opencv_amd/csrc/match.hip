@@ -82,7 +82,11 @@ struct PrepDesc { const float* src; size_t ld; int rows, dim, dim_pad, rows_pad;
 __global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl)
 {
     const PrepDesc d = tbl[blockIdx.y];
-    prep_l2_rows(d.src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, d.dst, d.norm, d.flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // table pointers are generic to the compiler; round-trip through the global address space so the loads/stores are global_*
+    const float* src = (const float*)(const float __attribute__((address_space(1)))*)(uintptr_t)d.src;
+    int8_t* dst = (int8_t*)(int8_t __attribute__((address_space(1)))*)(uintptr_t)d.dst;
+    int32_t* norm = (int32_t*)(int32_t __attribute__((address_space(1)))*)(uintptr_t)d.norm;
+    prep_l2_rows(src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, dst, norm, d.flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
 // Hamming2: rows into 64-byte zero-padded rows, re-encoded so that one dword carries 32 two-bit cells' LOW bits and
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void knn2_i8_kernel(const PairDesc* __restr
         }
         if (side == 0) {
             const int qrow = q0 + row;
-            const int qn = pd.qn[qrow];
+            const int qn = ((const int32_t __attribute__((address_space(1)))*)(uintptr_t)pd.qn)[qrow];
             long long k1 = KEY_INVALID, k2 = KEY_INVALID;
             if (m1 != INT_MAX) k1 = ((long long)((m1 >> 7) + qn) << 32) | (unsigned int)(t_begin + (m1 & 127) * 32 + i1);
             if (m2 != INT_MAX) k2 = ((long long)((m2 >> 7) + qn) << 32) | (unsigned int)(t_begin + (m2 & 127) * 32 + i2);
@@ -566,6 +570,9 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
     const PairDesc pd = pairs[blockIdx.z];
     const int dim = pd.dim, chunk = blockIdx.y;
     if (chunk >= pd.nchunks) return;
+    // (address-space casts: pointers read out of the PairDesc table are generic to the compiler -> flat_load otherwise)
+    typedef const float __attribute__((address_space(1)))* gf32;
+    const gf32 QF = (gf32)(uintptr_t)pd.qf, TF = (gf32)(uintptr_t)pd.tf;
     const int total = row_list ? row_count[blockIdx.z] : pd.nq;
     const int tid = threadIdx.x;
     const int t_begin = chunk * pd.chunk_rows;
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
         __syncthreads();
         for (int r = 0; r < QR; ++r) {
             const int row = rows[r] < 0 ? 0 : rows[r];
-            for (int k = tid; k < dim; k += 256) sm_q[r * dim + k] = pd.qf[(size_t)row * pd.ldq + k];
+            for (int k = tid; k < dim; k += 256) sm_q[r * dim + k] = QF[(size_t)row * pd.ldq + k];
         }
         __syncthreads();
 
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
         for (int r = 0; r < QR; ++r) { k1[r] = KEY_INVALID; k2[r] = KEY_INVALID; }
 
         for (int j = t_begin + tid; j < t_end; j += 256) {
-            const float* b = pd.tf + (size_t)j * pd.ldt;
+            const gf32 b = TF + (size_t)j * pd.ldt;
             float acc[QR][16];
 #pragma unroll
             for (int r = 0; r < QR; ++r)
@@ -600,8 +607,9 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
             for (; k <= dim - 16; k += 16) {
                 float bb[16];
                 if (ALIGNED) {
-                    const float4 b0 = *(const float4*)(b + k), b1 = *(const float4*)(b + k + 4);
-                    const float4 b2 = *(const float4*)(b + k + 8), b3 = *(const float4*)(b + k + 12);
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    typedef const f4v __attribute__((address_space(1)))* gf4;
+                    const f4v b0 = *(gf4)(b + k), b1 = *(gf4)(b + k + 4), b2 = *(gf4)(b + k + 8), b3 = *(gf4)(b + k + 12);
                     bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
                     bb[8] = b2.x; bb[9] = b2.y; bb[10] = b2.z; bb[11] = b2.w; bb[12] = b3.x; bb[13] = b3.y; bb[14] = b3.z; bb[15] = b3.w;
                 } else {
