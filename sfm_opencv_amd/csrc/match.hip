@@ -18,7 +18,13 @@
 #include <climits>
 #include <type_traits>
 
-#define KNN_BLOCK_ROWS 256     // train rows per staged block of knn2_i8_kernel; descriptor sets are padded to it
+#define KNN_BLOCK_ROWS 256     // descriptor sets are padded to a multiple of this (chunks of the kNN kernels are whole multiples)
+#ifndef KNN_STAGE_ROWS
+#define KNN_STAGE_ROWS 128     // train rows per staged LDS block of knn2_i8_kernel
+#endif
+#ifndef KNN_WGS_PER_CU
+#define KNN_WGS_PER_CU 4       // occupancy target of knn2_i8_kernel: 4 workgroups = 4 waves per SIMD (<= 128 VGPRs)
+#endif
 #define PAD_NORM 8388607      // 2^23-1: larger than any real partial key, never selected
 #define KEY_INVALID 0x7fffffffffffffffLL
 #define RESCORE_D2 4194304    // 2^22: below this, distinct integers have distinct float32 square roots
@@ -152,17 +158,25 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int off)
 // Partial output: for each (query row, chunk): two 64-bit keys (d2 << 32 | train index), ascending.
 // ------------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(256, 2) void knn2_i8_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part)
+__global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part, int n_pairs)
 {
     constexpr int DP = 32 * KS;          // bytes per row
     constexpr int CH = DP / 16;          // 16-byte chunks per row
-    constexpr int TROWS = KNN_BLOCK_ROWS, TILES = TROWS / 32;     // train rows staged per barrier
+    constexpr int TROWS = KNN_STAGE_ROWS, TILES = TROWS / 32;     // train rows staged per barrier
     constexpr int PASSES = (TROWS * CH) / 256;
     constexpr int BUF_BYTES = TROWS * DP, NORM_OFF = 2 * BUF_BYTES;
     constexpr int STAGE_BYTES = 2 * BUF_BYTES + 2 * TROWS * 4, MERGE_BYTES = 4 * 32 * 33 * 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
-    const PairDesc pd = pairs[blockIdx.z];
-    const int qb = blockIdx.x, chunk = blockIdx.y;
+    // XCD-aware work mapping (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs,
+    // each with its own L2, so pair 8g + k is given to the workgroups with id = k (mod 8): one XCD streams one train
+    // image instead of all eight fetching every image (TCC FETCH_SIZE of the C4 launch: 1.06 GB -> see profiles/).
+    // The grid's z extent is padded to a multiple of 8.
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per_pair = gridDim.x * gridDim.y, slot = lin >> 3;
+    const int pair = (slot / per_pair) * 8 + (lin & 7), rest = slot % per_pair;
+    if (pair >= n_pairs) return;
+    const PairDesc pd = pairs[pair];
+    const int qb = rest % gridDim.x, chunk = rest / gridDim.x;
     if (qb * 128 >= pd.nq_pad || chunk >= pd.nchunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -195,96 +209,79 @@ __global__ __launch_bounds__(256, 2) void knn2_i8_kernel(const PairDesc* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) { best1[i] = INT_MAX; best2[i] = INT_MAX; }
 
-    // Everything the loop addresses is a per-thread constant plus a compile-time offset (the block loop is unrolled
-    // by two so the LDS buffer is static): the VALU is the busiest unit of this kernel (PMC: SQ_ACTIVE_INST_VALU 74 %
-    // of the wall time), so the loop spends it on the top-2 epilogue only.
-    //   staging: thread -> 16-byte chunk cid = p*256 + tid of the 128 x DP block: global offset cid*16, LDS slot swizzled
-    //   operand reads: row tile*32 + l31, chunk (2 ks + half) ^ ((row >> 1) & (CH-1)); (row >> 1) & 7 does not depend on tile
-    // (chunk cid = p*256 + tid sits at global byte cid*16 and in row r = cid / CH; (r >> 1) & (CH-1) does not depend on p
-    //  when 256 / CH rows per pass is a multiple of 2*CH, so pass p is a compile-time offset on both sides)
-    static_assert((256 / CH) % (2 * CH) == 0 || PASSES == 1, "staging swizzle must repeat per pass");
+    // Staging is LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at M0 + lane*16, no staging registers and no
+    // ds_write): wave w's p-th instruction fills the 1 KB segment seg = 4p + w of the buffer, i.e. LDS chunk position
+    // (row r = 8 seg + lane/8, slot = lane%8); the XOR swizzle is applied on the GLOBAL side -- the lane fetches chunk
+    // c = slot ^ ((r >> 1) & (CH-1)) of row r -- so the operand reads below find chunk c of row r at slot c ^ ((r>>1)&(CH-1)).
+    // (r >> 1) & (CH-1) does not depend on p, so pass p is a uniform +p*4096 on both sides.
+    // Everything the loop addresses is a per-thread constant plus a compile-time offset: the VALU is the busiest unit of
+    // this kernel (PMC: SQ_ACTIVE_INST_VALU 74 % of the wall time), so the loop spends it on the top-2 epilogue only.
+    static_assert(DP == 128 || PASSES == 1 || (1024 / DP) % (2 * CH) == 0, "staging swizzle must repeat per pass");
+    typedef const char __attribute__((address_space(1)))* gbytes;
+    typedef char __attribute__((address_space(3)))* lbytes;
     int rd_off[KS];
-    const int st_goff = tid * 16;
-    const int st_loff = (tid / CH) * DP + 16 * ((tid % CH) ^ (((tid / CH) >> 1) & (CH - 1)));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) rd_off[ks] = l31 * DP + 16 * ((2 * ks + half) ^ ((l31 >> 1) & (CH - 1)));
+    const int seg_row = (wave * 1024 + lane * 16) / DP, seg_slot = ((wave * 1024 + lane * 16) % DP) / 16;
+    const int st_goff = seg_row * DP + 16 * (seg_slot ^ ((seg_row >> 1) & (CH - 1)));
     const int nrm_off = NORM_OFF + 4 * l31;
 
-    v4i stage[PASSES];
-    int stage_norm = 0;
-    auto g_load = [&](int blk) {
-        const gi8 blk_base = T + (size_t)(t_begin + blk * TROWS) * DP;        // wave-uniform
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) stage[p] = *(gv4)(blk_base + p * 4096 + st_goff);
-        // the train-side key term, complete: ((|b|^2 + 2 sum b) << 7) + first tile slot of the block; tile t adds t
-        if (tid < TROWS) stage_norm = TN[t_begin + blk * TROWS + tid] * 128 + blk * TILES + (tid >> 5);
-    };
-    auto l_store = [&](auto bufc) {
+    auto g_stage = [&](auto bufc, int blk) {
         constexpr int buf = decltype(bufc)::value;
+        const gbytes blk_base = (gbytes)(T + (size_t)(t_begin + blk * TROWS) * DP);      // wave-uniform
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) *(v4i*)(lds + st_loff + (buf * BUF_BYTES + p * (256 / CH) * DP)) = stage[p];
-        if (tid < TROWS) *(int*)(lds + NORM_OFF + buf * (4 * TROWS) + 4 * tid) = stage_norm;
+        for (int p = 0; p < PASSES; ++p)
+            __builtin_amdgcn_global_load_lds(blk_base + p * 4096 + st_goff, (lbytes)(lds + buf * BUF_BYTES + p * 4096 + wave * 1024), 16, 0, 0);
+        // train-side key terms (|b|^2 + 2 sum b), one dword per row
+        if (wave < TROWS / 64)
+            __builtin_amdgcn_global_load_lds((gbytes)(TN + t_begin + blk * TROWS + wave * 64 + lane),
+                                             (lbytes)(lds + NORM_OFF + buf * (4 * TROWS) + wave * 256), 4, 0, 0);
     };
     // one block of TROWS trains out of LDS buffer `buf`
-    auto compute = [&](auto bufc) {
+    auto compute = [&](auto bufc, int blk) {
         constexpr int buf = decltype(bufc)::value;
-        // Train fragments are requested one tile ahead of their MFMAs (8 live fragment registers sets instead of 16:
-        // 3 waves per SIMD instead of 2).  Tile t+1's MFMAs are interleaved with tile t's epilogue in fixed chunks
-        // (1 MFMA + 16/KS accumulators' worth of epilogue), fenced so the compiler keeps the order: the matrix pipe
-        // runs under the VALU work inside the wave.
-        v4i bfc[KS], bfn[KS];
+        // One tile at a time: 4 fragments, KS MFMAs, then the epilogue on the finished accumulator.  Nothing overlaps inside
+        // the wave on purpose -- this form needs <= 128 VGPRs, and FOUR resident waves per SIMD overlap each other's MFMA,
+        // VALU and LDS phases better than the software-pipelined 180-register form did with two (the epilogue mix issues at
+        // 2.0 ns per instruction per SIMD with 4 waves against 2.3 with 2, experiments/valu_bench.hip).
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bfc[ks] = *(const v4i*)(lds + rd_off[ks] + (buf * BUF_BYTES));
-        int nb_cur = 0, nb_next = *(const int*)(lds + nrm_off + (buf * (4 * TROWS)));
-        v16i acc_old = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int tile = 0; tile < TILES; ++tile) {
+            v4i bf[KS];
 #pragma unroll
-        for (int tile = 0; tile < TILES + 1; ++tile) {
-            nb_cur = nb_next;                     // tile - 1's key term while tile's MFMAs run
-            if (tile < TILES - 1) {
+            for (int ks = 0; ks < KS; ++ks) bf[ks] = *(const v4i*)(lds + rd_off[ks] + (buf * BUF_BYTES + tile * 32 * DP));
+            const int nbt = (*(const int*)(lds + nrm_off + (buf * (4 * TROWS) + tile * 128)) << 7) + (blk * TILES + tile);
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) bfn[ks] = *(const v4i*)(lds + rd_off[ks] + (buf * BUF_BYTES + (tile + 1) * 32 * DP));
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bf[ks], acc, 0, 0, 0);
+            // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
+            // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = (int)(((unsigned)acc[i] << 8) + (unsigned)nbt);
+                const int lo = best1[i] < best2[i] ? best1[i] : best2[i], hi = best1[i] < best2[i] ? best2[i] : best1[i];
+                const int t = hi < key ? hi : key;
+                best2[i] = lo > t ? lo : t;                                  // max(min(a,b), min(max(a,b), c)) = med3
+                best1[i] = best1[i] < key ? best1[i] : key;
+                asm volatile("" : "+v"(best1[i]), "+v"(best2[i]));          // pin here: LLVM otherwise sinks the whole epilogue below the barrier
             }
-            if (tile < TILES) nb_next = *(const int*)(lds + nrm_off + (buf * (4 * TROWS) + tile * 128));
-            v16i acc_new = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (tile < TILES) acc_new = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfc[ks], acc_new, 0, 0, 0);
-                if (tile > 0) {
-                    // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
-                    // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
-                    const int nbt = nb_cur;
-#pragma unroll
-                    for (int i = (16 / KS) * ks; i < (16 / KS) * (ks + 1); ++i) {
-                        const int key = (int)(((unsigned)acc_old[i] << 8) + (unsigned)nbt);
-                        const int lo = best1[i] < best2[i] ? best1[i] : best2[i], hi = best1[i] < best2[i] ? best2[i] : best1[i];
-                        const int t = hi < key ? hi : key;
-                        best2[i] = lo > t ? lo : t;                                  // max(min(a,b), min(max(a,b), c)) = med3
-                        best1[i] = best1[i] < key ? best1[i] : key;
-                        asm volatile("" : "+v"(best1[i]), "+v"(best2[i]));          // pin here: LLVM otherwise sinks the whole epilogue below the barrier
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc_old = acc_new;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bfc[ks] = bfn[ks];
         }
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
 
-    if (nblocks > 0) { g_load(0); l_store(B0{}); }
+#ifndef KNN_EXP
+#define KNN_EXP 0              // timing experiments only (wrong results): 1 = no staging / barriers after the first block
+#endif
+    if (nblocks > 0) g_stage(B0{}, 0);
     __syncthreads();
     for (int blk = 0; blk < nblocks; blk += 2) {
-        if (blk + 1 < nblocks) g_load(blk + 1);
-        compute(B0{});
-        if (blk + 1 < nblocks) l_store(B1{});
-        __syncthreads();
+        if (blk + 1 < nblocks && !(KNN_EXP & 1)) g_stage(B1{}, blk + 1);
+        compute(B0{}, blk);
+        if (!(KNN_EXP & 1)) __syncthreads();
         if (blk + 1 >= nblocks) break;
-        if (blk + 2 < nblocks) g_load(blk + 2);
-        compute(B1{});
-        if (blk + 2 < nblocks) l_store(B0{});
-        __syncthreads();
+        if (blk + 2 < nblocks && !(KNN_EXP & 1)) g_stage(B0{}, blk + 2);
+        compute(B1{}, blk + 1);
+        if (!(KNN_EXP & 1)) __syncthreads();
     }
 
     // Merge across the 32 lanes that share a query row, through LDS (the staging buffers are free after the last
@@ -1051,7 +1048,7 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
         d.nq = q->rows; d.nt = t->rows; d.nq_pad = q->rows_pad; d.nt_pad = t->rows_pad; d.dim = dim;
         if (P.path == 3) { d.q = q->d_u32; d.t = t->d_u32; }
         else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm + t->rows_pad; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
-        const int brows = (P.path == 2) ? KNN_BLOCK_ROWS : 128;               // rows per staged block of the kernel that runs
+        const int brows = (P.path == 2) ? KNN_STAGE_ROWS : 128;               // rows per staged block of the kernel that runs
         const int tblocks = d.nt_pad / brows, max_cb = 4096 / brows;          // <= 4096 train rows per chunk (7-bit tile index)
         int nch = (int)((target_wgs + qblocks_total - 1) / (qblocks_total > 0 ? qblocks_total : 1));
         if (P.path == 1) nch = 1 > nch ? 1 : (nch > 8 ? 8 : nch);
@@ -1115,11 +1112,11 @@ static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& 
     hipEvent_t* tev = (ctx->timing && ctx->timing_used < sfmhip_ctx::TIMING_SLOTS) ? ctx->tev[ctx->timing_used++] : nullptr;
     if (tev) (void)hipEventRecord(tev[0], ctx->stream);
     if (P.path == 2) {
-        const dim3 grid(P.max_qpad / 128, P.max_chunks, n_pairs);
+        const dim3 grid(P.max_qpad / 128, P.max_chunks, round_up(n_pairs, 8));       // z padded: see the kernel's XCD mapping
         switch (P.ks) {
-            case 1: hipLaunchKernelGGL(knn2_i8_kernel<1>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
-            case 2: hipLaunchKernelGGL(knn2_i8_kernel<2>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
-            case 4: hipLaunchKernelGGL(knn2_i8_kernel<4>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part); break;
+            case 1: hipLaunchKernelGGL(knn2_i8_kernel<1>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, n_pairs); break;
+            case 2: hipLaunchKernelGGL(knn2_i8_kernel<2>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, n_pairs); break;
+            case 4: hipLaunchKernelGGL(knn2_i8_kernel<4>, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, n_pairs); break;
             default: ctx->last_error = "int8 path: dim > 128"; return SFMHIP_E_ARG;
         }
         SFM_HIP_TRY(ctx, hipGetLastError());
