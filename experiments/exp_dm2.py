@@ -16,7 +16,7 @@ def run(ld, env):
     for _ in range(20): ctx.l2_distance_matrix_dev(qs, ts, out)
     e1.record(st); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 20
-variants = [("v1 bpw2", {}), ("v1 bpw1", {"SFMHIP_EXP_BPW": "1"}), ("v1 bpw3", {"SFMHIP_EXP_BPW": "3"})]
+variants = [("nt stores", {}), ("plain stores", {"SFMHIP_EXP_DISTMAT": "8"})]
 res = {v[0]: {10000: [], 10112: []} for v in variants}
 for rnd in range(3):
     for name, env in variants:

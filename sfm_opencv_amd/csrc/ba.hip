@@ -198,6 +198,9 @@ struct sfmhip_ba {
     int iter = 0, nsucc = 0, ninvalid = 0, termination = SFMHIP_BA_NO_CONVERGENCE;
     hipEvent_t ev[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // second stream: the Schur pair kernel runs beside the camera kernel
+    hipEvent_t evb[2][5] = {};          // per build parity: [start, camera kernel begin/end, pair kernel begin/end]
+    hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
+    bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
 
@@ -218,7 +221,7 @@ static int dupload(sfmhip_ba* h, T** p, const T* src, size_t count)
     return SFMHIP_OK;
 }
 
-static BADev make_dev(const sfmhip_ba* h, double radius)
+static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = false)
 {
     BADev P;
     memset(&P, 0, sizeof P);
@@ -237,6 +240,10 @@ static BADev make_dev(const sfmhip_ba* h, double radius)
     P.part_pt = h->d_part_pt; P.part_cam = h->d_part_cam; P.part_back = h->d_part_back;
     P.y = h->d_y;
     P.radius = radius; P.min_diag = h->o.min_lm_diagonal; P.max_diag = h->o.max_lm_diagonal;
+    if (at_candidate) {
+        P.K = h->d_Kc; P.ext = h->d_extc; P.pts = h->d_ptsc; P.Kc = h->d_K; P.extc = h->d_ext; P.ptsc = h->d_pts;
+        P.campre = h->d_campre_c; P.campre_c = h->d_campre;
+    }
     return P;
 }
 
@@ -248,30 +255,34 @@ static int call_allreduce(sfmhip_ba* h, double* buf, size_t count)
     return SFMHIP_OK;
 }
 
-// linearise at the current parameters: message = [S | rhs | diagU | graw | scal], summed over ranks, damped.
-static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp, bool timed = false)
+// linearise: message = [S | rhs | diagU | graw | scal] (undamped), summed over ranks.  at_candidate: at the candidate
+// parameters the last back-substitution produced (speculative build of the next iteration, see ba_loop).
+static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool timed)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
-    BADev P = make_dev(h, radius);
+    BADev P = make_dev(h, radius, at_candidate);       // the point blocks are damped with the radius while they are built
+    hipEvent_t* tv = nullptr;
+    if (timed) { h->build_parity ^= 1; tv = h->evb[h->build_parity]; (void)hipEventRecord(tv[0], st); }
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
     SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
-    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
+    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, at_candidate ? h->d_extc : h->d_ext, h->nc,
+                       at_candidate ? h->d_campre_c : h->d_campre);
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
-    // The camera kernel (one wave per SIMD: 80 fp64 accumulators per thread) and the Schur pair kernel both depend only on
-    // the point kernel and both leave most of the chip's issue slots idle, so they run side by side: the pair kernel on
-    // the auxiliary stream, its partials folded into S (ba_schur_reduce_kernel, the only writer) after the join.
+    // The camera kernel and the Schur pair kernel both depend only on the point kernel and both leave issue slots idle, so
+    // they run side by side: the pair kernel on the auxiliary stream, its partials folded into S (ba_schur_reduce_kernel,
+    // the only writer) after the join.
     if (h->nblk > 0) {
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        if (timed) (void)hipEventRecord(h->ev[6], h->aux);
+        if (tv) (void)hipEventRecord(tv[3], h->aux);
         hipLaunchKernelGGL(ba_schur_kernel, dim3(ceil_div(h->nchunk, 4)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
-        if (timed) (void)hipEventRecord(h->ev[7], h->aux);
+        if (tv) (void)hipEventRecord(tv[4], h->aux);
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
-    } else if (timed) { (void)hipEventRecord(h->ev[6], st); (void)hipEventRecord(h->ev[7], st); }
-    if (timed) (void)hipEventRecord(h->ev[4], st);
+    } else if (tv) { (void)hipEventRecord(tv[3], st); (void)hipEventRecord(tv[4], st); }
+    if (tv) (void)hipEventRecord(tv[1], st);
     hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split, h->fixK ? 1 : 2), dim3(256), 0, st, P);     // z = 1: camera-intrinsic sums
-    if (timed) (void)hipEventRecord(h->ev[5], st);
+    if (tv) (void)hipEventRecord(tv[2], st);
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
     if (h->nblk > 0) {
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
@@ -289,8 +300,23 @@ static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp, bool timed 
                            h->d_msg + np2, tail, h->d_pack, 1);
         SFM_HIP_TRY(ctx, hipGetLastError());
     }
-    if (damp) { hipLaunchKernelGGL(ba_damp_kernel, dim3(1), dim3(256), 0, st, P); SFM_HIP_TRY(ctx, hipGetLastError()); }
     return SFMHIP_OK;
+}
+
+static int enqueue_damp(sfmhip_ba* h, double radius)
+{
+    BADev P = make_dev(h, radius);
+    hipLaunchKernelGGL(ba_damp_kernel, dim3(1), dim3(256), 0, h->ctx->stream, P);
+    SFM_HIP_TRY(h->ctx, hipGetLastError());
+    return SFMHIP_OK;
+}
+
+// linearise at the current parameters (+ damping): start-up and sfmhip_ba_reduced_system
+static int enqueue_linearize(sfmhip_ba* h, double radius, bool damp)
+{
+    h->built = false;
+    int rc = enqueue_build(h, radius, false, false); if (rc) return rc;
+    return damp ? enqueue_damp(h, radius) : SFMHIP_OK;
 }
 
 static int enqueue_solve(sfmhip_ba* h)
@@ -549,11 +575,20 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
     const int it_end = h->iter + max_it;
     const size_t np2 = (size_t)h->npad * h->npad;
     const double* d_scal = h->d_msg + np2 + 3 * (size_t)h->npad;
+    // Per iteration the host needs four scalars back before it can accept or reject the step.  SFMHIP_SPECULATE=1 enqueues
+    // the NEXT linearisation at the candidate parameters right behind the scalar copies (guessing the radius growth of a
+    // good step), so that an accepted step finds its build already running.  Measured at C4: 11 of 12 guesses hit, results
+    // bit-identical, but no gain (0.695 vs 0.686 ms per step): the round trip is ~10 us of a 0.67 ms iteration and the extra
+    // enqueue work costs as much.  Off by default.
+    static const bool speculate = getenv("SFMHIP_SPECULATE") != nullptr;
     for (;;) {
         if (h->iter >= it_end) { h->termination = SFMHIP_BA_NO_CONVERGENCE; break; }
         if (!forced && h->radius < o.min_trust_region_radius) { h->termination = SFMHIP_BA_CONVERGENCE; break; }
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev[0], st));
-        int rc = enqueue_linearize(h, h->radius, true, true); if (rc) return rc;
+        int rc = SFMHIP_OK;
+        if (!h->built) { rc = enqueue_build(h, h->radius, false, true); if (rc) return rc; }
+        const int par = h->build_parity;            // events of the build this iteration consumes
+        h->built = false;                           // damping and the in-place factorisation consume it
+        rc = enqueue_damp(h, h->radius); if (rc) return rc;
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev[1], st));
         rc = enqueue_solve(h); if (rc) return rc;
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev[2], st));
@@ -563,12 +598,18 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 2, h->d_back4, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 6, h->d_cam2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 8, h->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-        SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
+        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
+        // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
+        // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
+        bool speculated = false;
+        const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
+        if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
+        SFM_HIP_TRY(ctx, hipEventSynchronize(h->ev_scal));
         {
             float a = 0, b = 0, c = 0, k1 = 0, k2 = 0, k3 = 0;
-            (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]); (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+            (void)hipEventElapsedTime(&a, h->evb[par][0], h->ev[1]); (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
             (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-            (void)hipEventElapsedTime(&k1, h->ev[4], h->ev[5]); (void)hipEventElapsedTime(&k2, h->ev[6], h->ev[7]);
+            (void)hipEventElapsedTime(&k1, h->evb[par][1], h->evb[par][2]); (void)hipEventElapsedTime(&k2, h->evb[par][3], h->evb[par][4]);
             if (h->use_sparse && h->nseg > 1) (void)hipEventElapsedTime(&k3, h->ev[8], h->ev[9]);
             h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c;
             h->phase_acc[4] += k1; h->phase_acc[5] += k2; h->phase_acc[6] += k3; h->phase_cnt++;
@@ -595,10 +636,12 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
             const double rho = cost_change / mcc;
             if (rho > o.min_relative_decrease) {
                 std::swap(h->d_K, h->d_Kc); std::swap(h->d_ext, h->d_extc); std::swap(h->d_pts, h->d_ptsc);
+                std::swap(h->d_campre, h->d_campre_c);
                 h->x_norm = std::sqrt(xn); h->x_cost = cand;
                 const double t = 2.0 * rho - 1.0;
                 h->radius = h->radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
                 h->radius = std::min(o.max_trust_region_radius, h->radius);
+                h->built = speculated && h->radius == spec_radius;      // built at what is now the current point, with the radius it guessed
                 h->nu = 2.0; ++h->nsucc; accepted = true;
             } else {
                 h->radius = h->radius / h->nu; h->nu *= 2.0;
@@ -648,6 +691,8 @@ void sfmhip_ba_destroy(sfmhip_ba* h)
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    for (auto& pr : h->evb) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
+    if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -762,6 +807,8 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
 #undef TRY_RC
     if (hipHostMalloc((void**)&h->h_scal, 16 * sizeof(double)) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipHostMalloc"; return SFMHIP_E_HIP; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
+    for (auto& pr : h->evb) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
+    if (hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "auxiliary stream"; return SFMHIP_E_HIP; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "upload failed"; return SFMHIP_E_HIP; }
@@ -773,7 +820,7 @@ int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, in
 {
     if (!h || world < 1 || world > 64 || rank < 0 || rank >= world) return SFMHIP_E_ARG;
     h->ar_fn = fn; h->ar_user = user; h->rank = rank; h->world = world;
-    h->started = false;
+    h->started = false; h->built = false;
     return SFMHIP_OK;
 }
 
@@ -784,7 +831,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_K, h->d_K0, 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ext, h->d_ext0, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (h->np) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts, h->d_pts0, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    h->started = false;
+    h->started = false; h->built = false;
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     return SFMHIP_OK;
 }
@@ -793,7 +840,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
-    h->started = false;
+    h->started = false; h->built = false;
     const int rc = ba_loop(h, h->o.max_num_iterations, false);
     fill_summary(h, summary, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;
