@@ -154,6 +154,17 @@ int sfmhip_triangulate2_matches_dev(sfmhip_ctx*, const float P1[12], const float
                                     const sfm_keypoint* d_kp1, const sfm_keypoint* d_kp2,
                                     const sfm_dmatch* d_matches, int n, float* d_xyzw, double* d_xyz);
 
+/* N-view extension (SURVEY 8f rank 4 -- NOT reference behaviour: the reference triangulates a point once, from the pair
+ * that created it, NView:1428-1453).  Multi-view DLT of every track from ALL its observations, on normalised image
+ * coordinates ((u-cx)/fx, (v-cy)/fy) with [R|t] from the angle-axis extrinsics of the BA parameterisation (NView:151-183,
+ * 1464-1487); points with fewer than two observations come back as NaN.  n_views_out (may be NULL) = observations used.
+ * sfmhip_reprojection_errors: pixel error |K (R X + t)/z - uv| of every observation, e.g. to filter tracks after BA. */
+int  sfmhip_triangulate_tracks(sfmhip_ctx* ctx, const double K4[4], const double* ext6, int n_cam,
+                               const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, int n_pt,
+                               double* pts_out, int32_t* n_views_out);
+int  sfmhip_reprojection_errors(sfmhip_ctx* ctx, const double K4[4], const double* ext6, int n_cam, const double* pts, int n_pt,
+                                const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, double* err_out);
+
 /* ------------------------------------------------------------------------------------------ */
 /* bundle adjustment: replaces bundle_adjustment (NView:1162-1244) = ceres::Solve on            */
 /* AutoDiffCostFunction<ReprojectCost,2,4,6,3> (NView:142-184) + HuberLoss(4) + SPARSE_SCHUR.   */

@@ -145,6 +145,24 @@ def ba_default_options(**kw):
     return o
 
 
+def triangulate_tracks(K4, ext, obs_cam, obs_pt, obs_uv, n_pt):
+    K4 = np.ascontiguousarray(K4, np.float64); ext = np.ascontiguousarray(ext, np.float64)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32); uv = np.ascontiguousarray(obs_uv, np.float64)
+    pts = np.empty((n_pt, 3), np.float64); nv = np.empty(n_pt, np.int32)
+    lib().orc_triangulate_tracks(_p(K4, C.c_double), _p(ext, C.c_double), ext.shape[0], _p(oc, C.c_int32), _p(op, C.c_int32),
+                                 _p(uv, C.c_double), oc.shape[0], n_pt, _p(pts, C.c_double), _p(nv, C.c_int32))
+    return pts, nv
+
+
+def reprojection_errors(K4, ext, pts, obs_cam, obs_pt, obs_uv):
+    K4 = np.ascontiguousarray(K4, np.float64); ext = np.ascontiguousarray(ext, np.float64); pts = np.ascontiguousarray(pts, np.float64)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32); uv = np.ascontiguousarray(obs_uv, np.float64)
+    err = np.empty(oc.shape[0], np.float64)
+    lib().orc_reprojection_errors(_p(K4, C.c_double), _p(ext, C.c_double), ext.shape[0], _p(pts, C.c_double), _p(oc, C.c_int32),
+                                  _p(op, C.c_int32), _p(uv, C.c_double), oc.shape[0], _p(err, C.c_double))
+    return err
+
+
 def reproject(K4, ext6, X, uv):
     K4 = np.ascontiguousarray(K4, np.float64); ext6 = np.ascontiguousarray(ext6, np.float64)
     X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)

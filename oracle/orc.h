@@ -48,6 +48,12 @@ void orc_triangulate2(const float P1[12], const float P2[12], const float* xy1, 
 /* NView:1129-1143: P = float(K) * [float(R) | float(T)] in float32 (cv::Mat float gemm [3P]) */
 void orc_projection_matrix(const double K[9], const double R[9], const double T[3], float P[12]);
 
+/* N-view DLT on normalised coordinates + per-observation reprojection error (extension; see orc_triangulate.c) */
+void orc_triangulate_tracks(const double K4[4], const double* ext6, int n_cam, const int32_t* obs_cam, const int32_t* obs_pt,
+                            const double* obs_uv, int n_obs, int n_pt, double* pts, int32_t* n_views);
+void orc_reprojection_errors(const double K4[4], const double* ext6, int n_cam, const double* pts, const int32_t* obs_cam,
+                             const int32_t* obs_pt, const double* obs_uv, int n_obs, double* err);
+
 /* ---- bundle adjustment (NView:142-184, 1162-1244 + Ceres defaults [3P]) ---- */
 typedef struct {
     int    max_num_iterations;

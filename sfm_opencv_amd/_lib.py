@@ -50,6 +50,7 @@ SYMBOLS = [
     "sfmhip_match_features_l2", "sfmhip_match_features_hamming2",
     "sfmhip_match_pairs_dev", "sfmhip_match_pairs", "sfmhip_l2_distance_matrix_dev",
     "sfmhip_triangulate2_f32", "sfmhip_triangulate2_f32_dev", "sfmhip_triangulate2_matches_dev",
+    "sfmhip_triangulate_tracks", "sfmhip_reprojection_errors",
     "sfmhip_ba_default_options", "sfmhip_ba_solve", "sfmhip_ba_create", "sfmhip_ba_destroy",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_run", "sfmhip_ba_iterate", "sfmhip_ba_reset",
     "sfmhip_ba_get_params", "sfmhip_ba_reduced_system", "sfmhip_ba_phase_ms",
@@ -104,6 +105,8 @@ def load():
         "sfmhip_triangulate2_f32": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
         "sfmhip_triangulate2_f32_dev": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
         "sfmhip_triangulate2_matches_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+        "sfmhip_triangulate_tracks": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp]),
+        "sfmhip_reprojection_errors": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "sfmhip_ba_default_options": (None, [C.POINTER(BAOptions)]),
         "sfmhip_ba_solve": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(BAOptions), C.POINTER(BASummary)]),
         "sfmhip_ba_create": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(BAOptions), C.POINTER(vp)]),

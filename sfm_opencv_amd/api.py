@@ -197,6 +197,24 @@ class Context:
                                                              _ptr(matches), n, _ptr(xyzw), _ptr(xyz)))
 
     # ---------------------------------------------------------------- bundle adjustment
+    def triangulate_tracks(self, K4, ext, obs_cam, obs_pt, obs_uv, n_pt):
+        """N-view DLT of every track (extension, sfmhip_triangulate_tracks): returns (pts (n_pt,3) float64, n_views int32)."""
+        K4 = np.ascontiguousarray(K4, np.float64); ext = np.ascontiguousarray(ext, np.float64)
+        oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32); uv = np.ascontiguousarray(obs_uv, np.float64)
+        pts = np.empty((n_pt, 3), np.float64); nv = np.empty(n_pt, np.int32)
+        self._check(self.lib.sfmhip_triangulate_tracks(self.h, _ptr(K4), _ptr(ext), ext.shape[0], _ptr(oc), _ptr(op), _ptr(uv),
+                                                       oc.shape[0], int(n_pt), _ptr(pts), _ptr(nv)))
+        return pts, nv
+
+    def reprojection_errors(self, K4, ext, pts, obs_cam, obs_pt, obs_uv):
+        """pixel error of every observation (sfmhip_reprojection_errors)"""
+        K4 = np.ascontiguousarray(K4, np.float64); ext = np.ascontiguousarray(ext, np.float64); pts = np.ascontiguousarray(pts, np.float64)
+        oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32); uv = np.ascontiguousarray(obs_uv, np.float64)
+        err = np.empty(oc.shape[0], np.float64)
+        self._check(self.lib.sfmhip_reprojection_errors(self.h, _ptr(K4), _ptr(ext), ext.shape[0], _ptr(pts), pts.shape[0],
+                                                        _ptr(oc), _ptr(op), _ptr(uv), oc.shape[0], _ptr(err)))
+        return err
+
     def ba_options(self, **kw):
         o = BAOptions()
         self.lib.sfmhip_ba_default_options(C.byref(o))

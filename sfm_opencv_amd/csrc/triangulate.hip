@@ -12,6 +12,8 @@
 // float32 results must be bit-exact with the CPU restatement: no FMA contraction, correctly rounded sqrt
 // (HIP's __fsqrt_rn/__fmul_rn are NOT the rounded forms on this toolchain: native sqrt / contractible mul).
 #pragma clang fp contract(off)
+#include <cmath>
+#include <vector>
 
 struct ProjPair { float p1[12]; float p2[12]; };
 
@@ -103,6 +105,84 @@ __global__ __launch_bounds__(256) void triangulate2_matches_kernel(ProjPair P, c
     store_point(h, i, n, xyzw, xyz);
 }
 
+// ------------------------------------------------------------------------------------------------
+// N-view extension (not reference behaviour): multi-view DLT of every track on normalised image
+// coordinates, and per-observation reprojection errors.  Thread per point walks its observation list (CSR by point);
+// the 4x4 moment matrix M = A'A stays in registers and goes through the same Jacobi routine as the two-view system.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triangulate_tracks_kernel(const double* __restrict__ Rt, double fx, double fy, double cx, double cy,
+                                                                 const int* __restrict__ pt_start, const int* __restrict__ ocam,
+                                                                 const double* __restrict__ ouv, int n_pt,
+                                                                 double* __restrict__ pts, int* __restrict__ n_views)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pt) return;
+    const int s0 = pt_start[p], s1 = pt_start[p + 1];
+    double A[4][4], V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { A[i][j] = 0.0; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int q = s0; q < s1; ++q) {
+        const double* P = Rt + 12 * (size_t)ocam[q];
+        const double xn = (ouv[2 * q] - cx) / fx, yn = (ouv[2 * q + 1] - cy) / fy;
+        double r0[4], r1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r0[j] = xn * P[8 + j] - P[j]; r1[j] = yn * P[8 + j] - P[4 + j]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[i][j] += r0[i] * r0[j] + r1[i] * r1[j];
+    }
+    if (n_views) n_views[p] = s1 - s0;
+    if (s1 - s0 < 2) { const double nan = __longlong_as_double(0x7ff8000000000000LL); pts[3 * p] = pts[3 * p + 1] = pts[3 * p + 2] = nan; return; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        jacobi_rot(A, V, 0, 1, rotated); jacobi_rot(A, V, 0, 2, rotated); jacobi_rot(A, V, 0, 3, rotated);
+        jacobi_rot(A, V, 1, 2, rotated); jacobi_rot(A, V, 1, 3, rotated); jacobi_rot(A, V, 2, 3, rotated);
+        if (!rotated) break;
+    }
+    double best = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 1.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double nn = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nn += A[i][j] * A[i][j];
+        if (j == 0 || nn < best) { best = nn; v0 = V[0][j]; v1 = V[1][j]; v2 = V[2][j]; v3 = V[3][j]; }
+    }
+    pts[3 * p] = v0 / v3; pts[3 * p + 1] = v1 / v3; pts[3 * p + 2] = v2 / v3;
+}
+
+__global__ __launch_bounds__(256) void reprojection_error_kernel(const double* __restrict__ Rt, double fx, double fy, double cx, double cy,
+                                                                 const double* __restrict__ pts, const int* __restrict__ ocam,
+                                                                 const int* __restrict__ opt, const double* __restrict__ ouv, int n_obs,
+                                                                 double* __restrict__ err)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_obs) return;
+    const double* P = Rt + 12 * (size_t)ocam[k]; const double* X = pts + 3 * (size_t)opt[k];
+    const double x = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3], y = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+    const double z = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+    const double du = fx * x / z + cx - ouv[2 * k], dv = fy * y / z + cy - ouv[2 * k + 1];
+    err[k] = sqrt(du * du + dv * dv);
+}
+
+// angle-axis + translation -> [R | t] (row-major 3x4), the rotation formula of the BA cost (NView:151-183)
+static void angle_axis_to_Rt(const double* e, double Rt[12])
+{
+    const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    double R[9];
+    if (th2 > 2.220446049250313e-16) {
+        const double th = std::sqrt(th2), c = std::cos(th), s = std::sin(th), wx = e[0] / th, wy = e[1] / th, wz = e[2] / th, k = 1.0 - c;
+        R[0] = c + wx * wx * k;      R[1] = wx * wy * k - wz * s; R[2] = wx * wz * k + wy * s;
+        R[3] = wy * wx * k + wz * s; R[4] = c + wy * wy * k;      R[5] = wy * wz * k - wx * s;
+        R[6] = wz * wx * k - wy * s; R[7] = wz * wy * k + wx * s; R[8] = c + wz * wz * k;
+    } else {
+        R[0] = 1; R[1] = -e[2]; R[2] = e[1]; R[3] = e[2]; R[4] = 1; R[5] = -e[0]; R[6] = -e[1]; R[7] = e[0]; R[8] = 1;
+    }
+    for (int r = 0; r < 3; ++r) { for (int c2 = 0; c2 < 3; ++c2) Rt[4 * r + c2] = R[3 * r + c2]; Rt[4 * r + 3] = e[3 + r]; }
+}
+
 extern "C" {
 
 int sfmhip_triangulate2_f32_dev(sfmhip_ctx* ctx, const float P1[12], const float P2[12],
@@ -153,6 +233,74 @@ int sfmhip_triangulate2_f32(sfmhip_ctx* ctx, const float P1[12], const float P2[
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
     (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dw); (void)hipFree(dx);
     return rc;
+}
+
+
+int sfmhip_triangulate_tracks(sfmhip_ctx* ctx, const double K4[4], const double* ext6, int n_cam,
+                              const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, int n_pt,
+                              double* pts_out, int32_t* n_views_out)
+{
+    SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (pts_out || n_pt == 0));
+    SFM_ARG_CHECK(ctx, (obs_cam && obs_pt && obs_uv) || n_obs == 0);
+    for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);
+    if (n_pt == 0) return SFMHIP_OK;
+    // CSR by point, observations of a point in the caller's order (the accumulation order of M)
+    std::vector<int> pt_start(n_pt + 1, 0), fill(n_pt, 0), ocam(n_obs > 0 ? n_obs : 1);
+    std::vector<double> ouv(2 * (size_t)(n_obs > 0 ? n_obs : 1)), Rt(12 * (size_t)n_cam);
+    for (int k = 0; k < n_obs; ++k) pt_start[obs_pt[k] + 1]++;
+    for (int p = 0; p < n_pt; ++p) pt_start[p + 1] += pt_start[p];
+    for (int k = 0; k < n_obs; ++k) {
+        const int q = pt_start[obs_pt[k]] + fill[obs_pt[k]]++;
+        ocam[q] = obs_cam[k]; ouv[2 * (size_t)q] = obs_uv[2 * (size_t)k]; ouv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)k + 1];
+    }
+    for (int c = 0; c < n_cam; ++c) angle_axis_to_Rt(ext6 + 6 * c, Rt.data() + 12 * c);
+    const size_t b_rt = (Rt.size() * 8 + 255) / 256 * 256, b_st = (pt_start.size() * 4 + 255) / 256 * 256, b_oc = (ocam.size() * 4 + 255) / 256 * 256;
+    const size_t b_uv = (ouv.size() * 8 + 255) / 256 * 256, b_pt = ((size_t)n_pt * 24 + 255) / 256 * 256, b_nv = ((size_t)n_pt * 4 + 255) / 256 * 256;
+    void* base = nullptr;
+    int rc = sfm_scratch(ctx, b_rt + b_st + b_oc + b_uv + b_pt + b_nv, &base); if (rc) return rc;
+    char* c0 = (char*)base;
+    double* d_rt = (double*)c0; int* d_st = (int*)(c0 + b_rt); int* d_oc = (int*)(c0 + b_rt + b_st); double* d_uv = (double*)(c0 + b_rt + b_st + b_oc);
+    double* d_pt = (double*)(c0 + b_rt + b_st + b_oc + b_uv); int* d_nv = (int*)(c0 + b_rt + b_st + b_oc + b_uv + b_pt);
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_rt, Rt.data(), Rt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_st, pt_start.data(), pt_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_oc, ocam.data(), ocam.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_uv, ouv.data(), ouv.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(triangulate_tracks_kernel, dim3((n_pt + 255) / 256), dim3(256), 0, ctx->stream, d_rt, K4[0], K4[1], K4[2], K4[3],
+                       d_st, d_oc, d_uv, n_pt, d_pt, d_nv);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(pts_out, d_pt, (size_t)n_pt * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_views_out) SFM_HIP_TRY(ctx, hipMemcpyAsync(n_views_out, d_nv, (size_t)n_pt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SFMHIP_OK;
+}
+
+int sfmhip_reprojection_errors(sfmhip_ctx* ctx, const double K4[4], const double* ext6, int n_cam, const double* pts, int n_pt,
+                               const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, double* err_out)
+{
+    SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (err_out || n_obs == 0));
+    SFM_ARG_CHECK(ctx, n_obs == 0 || (pts && obs_cam && obs_pt && obs_uv));
+    for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);
+    if (n_obs == 0) return SFMHIP_OK;
+    std::vector<double> Rt(12 * (size_t)n_cam);
+    for (int c = 0; c < n_cam; ++c) angle_axis_to_Rt(ext6 + 6 * c, Rt.data() + 12 * c);
+    const size_t b_rt = (Rt.size() * 8 + 255) / 256 * 256, b_pt = ((size_t)n_pt * 24 + 255) / 256 * 256, b_i = ((size_t)n_obs * 4 + 255) / 256 * 256;
+    const size_t b_uv = ((size_t)n_obs * 16 + 255) / 256 * 256, b_e = ((size_t)n_obs * 8 + 255) / 256 * 256;
+    void* base = nullptr;
+    int rc = sfm_scratch(ctx, b_rt + b_pt + 2 * b_i + b_uv + b_e, &base); if (rc) return rc;
+    char* c0 = (char*)base;
+    double* d_rt = (double*)c0; double* d_pt = (double*)(c0 + b_rt); int* d_oc = (int*)(c0 + b_rt + b_pt); int* d_op = (int*)(c0 + b_rt + b_pt + b_i);
+    double* d_uv = (double*)(c0 + b_rt + b_pt + 2 * b_i); double* d_e = (double*)(c0 + b_rt + b_pt + 2 * b_i + b_uv);
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_rt, Rt.data(), Rt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_pt, pts, (size_t)n_pt * 24, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_oc, obs_cam, (size_t)n_obs * 4, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_op, obs_pt, (size_t)n_obs * 4, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(d_uv, obs_uv, (size_t)n_obs * 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(reprojection_error_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, ctx->stream, d_rt, K4[0], K4[1], K4[2], K4[3],
+                       d_pt, d_oc, d_op, d_uv, n_obs, d_e);
+    SFM_HIP_TRY(ctx, hipGetLastError());
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(err_out, d_e, (size_t)n_obs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SFMHIP_OK;
 }
 
 }  // extern "C"

@@ -100,3 +100,31 @@ def test_ba_observation_order_invariance():
     a = orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], force_iterations=5)[3]
     b = orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"][perm], sc["obs_pt"][perm], sc["obs_uv"][perm], force_iterations=5)[3]
     assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * a["final_cost"]
+
+
+def test_nview_dlt_oracle_vs_numpy_svd_and_truth():
+    """N-view extension: oracle vs numpy.linalg.svd of the stacked normalised system, and vs truth."""
+    sc = synth.ba_scene(9, 400, noise_px=0.0, outlier_frac=0.0, perturb=False)
+    pts, nv = orc.triangulate_tracks(sc["K_true"], sc["ext_true"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["n_pt"])
+    assert np.array_equal(nv, np.bincount(sc["obs_pt"], minlength=sc["n_pt"]))
+    assert np.abs(pts - sc["pts_true"]).max() < 1e-9            # noise-free: the exact point
+    scn = synth.ba_scene(9, 400, outlier_frac=0.0, perturb=False)    # 0.5 px noise
+    pts, _ = orc.triangulate_tracks(scn["K_true"], scn["ext_true"], scn["obs_cam"], scn["obs_pt"], scn["obs_uv"], scn["n_pt"])
+    K = scn["K_true"]
+    for p in range(0, 400, 37):
+        sel = np.nonzero(scn["obs_pt"] == p)[0]
+        rows = []
+        for k in sel:
+            R = synth.angle_axis_to_rotmat(scn["ext_true"][scn["obs_cam"][k], :3]); t = scn["ext_true"][scn["obs_cam"][k], 3:]
+            Rt = np.hstack([R, t[:, None]])
+            xn = (scn["obs_uv"][k, 0] - K[2]) / K[0]; yn = (scn["obs_uv"][k, 1] - K[3]) / K[1]
+            rows += [xn * Rt[2] - Rt[0], yn * Rt[2] - Rt[1]]
+        v = np.linalg.svd(np.array(rows))[2][-1]
+        assert np.abs(pts[p] - v[:3] / v[3]).max() < 1e-9
+    err = orc.reprojection_errors(K, scn["ext_true"], pts, scn["obs_cam"], scn["obs_pt"], scn["obs_uv"])
+    uv = synth.project(K, scn["ext_true"][scn["obs_cam"]], pts[scn["obs_pt"]])
+    assert np.abs(err - np.linalg.norm(uv - scn["obs_uv"], axis=1)).max() < 1e-9
+    assert np.median(err) < 1.0
+    # fewer than two observations -> NaN
+    one = orc.triangulate_tracks(K, scn["ext_true"], scn["obs_cam"][:1], np.zeros(1, np.int32), scn["obs_uv"][:1], 2)
+    assert np.isnan(one[0]).all() and list(one[1]) == [1, 0]

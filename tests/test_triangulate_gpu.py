@@ -56,3 +56,26 @@ def test_fused_gather_triangulation(ctx):
     ctx.synchronize()
     _, ref = ctx.triangulate2(P1, P2, s["xy1"], s["xy2"])
     assert np.array_equal(xyz.cpu().numpy(), ref)
+
+
+def test_nview_tracks_and_reprojection_errors_match_oracle(ctx):
+    """N-view DLT extension (sfmhip_triangulate_tracks) and per-observation pixel errors vs the oracle; fp64, 1e-10."""
+    sc = synth.ba_scene(40, 20000, perturb=False)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(sc["n_obs"])                          # the entry point must not depend on the observation order
+    args = (sc["K_true"], sc["ext_true"], sc["obs_cam"][perm], sc["obs_pt"][perm], sc["obs_uv"][perm])
+    pts, nv = ctx.triangulate_tracks(*args, sc["n_pt"])
+    opts, onv = orc.triangulate_tracks(*args, sc["n_pt"])
+    assert np.array_equal(nv, onv)
+    scale = np.abs(opts).max()
+    assert np.abs(pts - opts).max() <= 1e-10 * scale
+    # with 0.5 px noise and 2 % outlier pixels most tracks land within a few 1e-3 of the truth
+    assert np.median(np.linalg.norm(pts - sc["pts_true"], axis=1)) < 5e-3
+    err = ctx.reprojection_errors(sc["K_true"], sc["ext_true"], pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    oerr = orc.reprojection_errors(sc["K_true"], sc["ext_true"], pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    assert np.abs(err - oerr).max() <= 1e-9 * max(oerr.max(), 1.0)
+    # the gross outliers (2 % of the pixels were moved by up to 50 px) stand out
+    assert 0.01 < (err > 5.0).mean() < 0.10      # an outlier pixel also drags the other observations of its track
+    # ragged input: a point with a single observation and one with none
+    p2, n2 = ctx.triangulate_tracks(sc["K_true"], sc["ext_true"], sc["obs_cam"][:1], np.zeros(1, np.int32), sc["obs_uv"][:1], 2)
+    assert np.isnan(p2).all() and list(n2) == [1, 0]
