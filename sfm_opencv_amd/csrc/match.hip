@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
     const PairDesc pd = pairs[pair];
     const int qb = rest % gridDim.x, chunk = rest / gridDim.x;
     if (qb * 128 >= pd.nq_pad || chunk >= pd.nchunks) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it (and every address built from it) in SGPRs
     const int l31 = lane & 31, half = lane >> 5;
     // pointers that come out of the PairDesc table are generic to the compiler: without the address-space casts the
     // train prefetch becomes flat_load, which also counts in lgkmcnt -- every LDS wait then waits for HBM as well
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) rd_off[ks] = l31 * DP + 16 * ((2 * ks + half) ^ ((l31 >> 1) & (CH - 1)));
     const int seg_row = (wave * 1024 + lane * 16) / DP, seg_slot = ((wave * 1024 + lane * 16) % DP) / 16;
-    const int st_goff = seg_row * DP + 16 * (seg_slot ^ ((seg_row >> 1) & (CH - 1)));
+    const unsigned st_goff = (unsigned)(seg_row * DP + 16 * (seg_slot ^ ((seg_row >> 1) & (CH - 1))));     // unsigned: lets hipcc use the SGPR-base + 32-bit VGPR-offset form
     const int nrm_off = NORM_OFF + 4 * l31;
 
     auto g_stage = [&](auto bufc, int blk) {
@@ -231,11 +232,18 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
         const gbytes blk_base = (gbytes)(T + (size_t)(t_begin + blk * TROWS) * DP);      // wave-uniform
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
-            __builtin_amdgcn_global_load_lds(blk_base + p * 4096 + st_goff, (lbytes)(lds + buf * BUF_BYTES + p * 4096 + wave * 1024), 16, 0, 0);
+        {
+            unsigned long long pb = (unsigned long long)(uintptr_t)(blk_base + p * 4096);
+            asm volatile("" : "+s"(pb));          // keep the per-pass base in SGPRs: one VGPR offset serves all passes
+            __builtin_amdgcn_global_load_lds((gbytes)pb + st_goff, (lbytes)(lds + buf * BUF_BYTES + p * 4096 + wave * 1024), 16, 0, 0);
+        }
         // train-side key terms (|b|^2 + 2 sum b), one dword per row
         if (wave < TROWS / 64)
-            __builtin_amdgcn_global_load_lds((gbytes)(TN + t_begin + blk * TROWS + wave * 64 + lane),
-                                             (lbytes)(lds + NORM_OFF + buf * (4 * TROWS) + wave * 256), 4, 0, 0);
+        {
+            unsigned long long nb = (unsigned long long)(uintptr_t)(TN + t_begin + blk * TROWS + wave * 64);
+            asm volatile("" : "+s"(nb));
+            __builtin_amdgcn_global_load_lds((gbytes)nb + (unsigned)(4 * lane), (lbytes)(lds + NORM_OFF + buf * (4 * TROWS) + wave * 256), 4, 0, 0);
+        }
     };
     // one block of TROWS trains out of LDS buffer `buf`
     auto compute = [&](auto bufc, int blk) {
