@@ -7,7 +7,7 @@ q = torch.from_numpy(dd[0]).cuda(); t = torch.from_numpy(dd[1]).cuda()
 qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
 outs = {ld: torch.empty((10000, ld), dtype=torch.float32, device="cuda") for ld in (10000, 10112)}
 def run(ld, env):
-    for k in ("SFMHIP_DISTMAT_V2", "SFMHIP_EXP_TPW", "SFMHIP_EXP_NT", "SFMHIP_EXP_DISTMAT", "SFMHIP_EXP_BPW"): os.environ.pop(k, None)
+    for k in ("SFMHIP_EXP_DISTMAT", "SFMHIP_EXP_BPW"): os.environ.pop(k, None)
     os.environ.update(env)
     out = outs[ld]
     for _ in range(3): ctx.l2_distance_matrix_dev(qs, ts, out)

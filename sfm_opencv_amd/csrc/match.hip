@@ -483,81 +483,6 @@ __global__ void sqrt_check_kernel(int* __restrict__ mismatches)
     if (__float_as_int(sqrt_exact_int(x)) != __float_as_int(sqrtf(x))) atomicAdd(mismatches, 1);
 }
 
-// v2 of the materialised distance matrix: no LDS staging of the operands and no workgroup barriers.  The whole
-// descriptor set is L2-resident (2.6 MB at 10k x 128 B), so each wave streams its train fragments straight from
-// L2/L1 into registers one tile ahead, keeps its 32 query rows stationary, and only uses LDS for its private
-// output slab (full-line stores).  The 4 waves of a workgroup walk the same trains (L1 reuse) but never synchronise.
-// grid = (query blocks of 128, train chunks of TPW tiles), block = 256.
-template <int KS>
-__global__ __launch_bounds__(256) void distmat_i8_v2_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
-                                                            const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
-                                                            int nq, int nt, int nt_pad, int tiles_per_wave,
-                                                            float* __restrict__ dist, size_t ldd, int vec_ok, int use_nt)
-{
-    constexpr int DP = 32 * KS;
-    __shared__ __attribute__((aligned(16))) float stage_out[4 * 32 * 36];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int t_begin = blockIdx.y * tiles_per_wave * 32;
-    int ntiles = (nt_pad - t_begin) / 32; if (ntiles > tiles_per_wave) ntiles = tiles_per_wave;
-    if (ntiles <= 0) return;
-    v4i qfrag[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qfrag[ks] = *(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
-    const int qn = qnorm[q0 + l31];
-    float* slab = stage_out + wave * (32 * 36);
-
-    v4i a_next[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_next[ks] = *(const v4i*)(T + (size_t)(t_begin + l31) * DP + 32 * ks + 16 * half);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int tg0 = t_begin + tile * 32;
-        v4i a_cur[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_next[ks];
-        if (tile + 1 < ntiles) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a_next[ks] = *(const v4i*)(T + (size_t)(tg0 + 32 + l31) * DP + 32 * ks + 16 * half);
-        }
-        v4i tn[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) tn[g] = *(const v4i*)(tnorm + tg0 + 8 * g + 4 * half);
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[ks], qfrag[ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 o;
-            o.x = sqrt_exact_int((float)(qn + tn[g].x - 2 * acc[4 * g + 0]));
-            o.y = sqrt_exact_int((float)(qn + tn[g].y - 2 * acc[4 * g + 1]));
-            o.z = sqrt_exact_int((float)(qn + tn[g].z - 2 * acc[4 * g + 2]));
-            o.w = sqrt_exact_int((float)(qn + tn[g].w - 2 * acc[4 * g + 3]));
-            *(float4*)(slab + l31 * 36 + 8 * g + 4 * half) = o;
-        }
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 4;
-            const float4 o = *(const float4*)(slab + row * 36 + col);
-            const int qr = q0 + row, tg = tg0 + col;
-            if (qr < nq) {
-                float* dst = dist + (size_t)qr * ldd + tg;
-                if (vec_ok && tg + 3 < nt) {
-                    v4f ov = { o.x, o.y, o.z, o.w };
-                    // rows that start on a 128-byte boundary: nontemporal full-line stores (measured 5.07 vs 4.92 TB/s);
-                    // rows at a 64-byte offset (ld = 10000): plain stores, the L2 merges the half lines (4.27 vs 3.87 TB/s)
-                    if (use_nt) __builtin_nontemporal_store(ov, (v4f*)dst); else *(v4f*)dst = ov;
-                } else {
-                    if (tg + 0 < nt) dst[0] = o.x;
-                    if (tg + 1 < nt) dst[1] = o.y;
-                    if (tg + 2 < nt) dst[2] = o.z;
-                    if (tg + 3 < nt) dst[3] = o.w;
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // exact fp32 path (general float descriptors, and re-scoring of rows flagged by the merge).
 // One block handles QR query rows against the trains of one chunk; thread = train row.
@@ -1317,19 +1242,6 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
         const dim3 grid(query->rows_pad / 128, ceil_div(train->rows_pad / 128, bpw));
         const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
         const int ks = query->dim_pad / 32;
-        if (getenv("SFMHIP_DISTMAT_V2")) {          // alternative without LDS operand staging: measured slower (138 vs 108 us)
-            const char* et = getenv("SFMHIP_EXP_TPW");
-            const int tpw = et ? atoi(et) : 8;
-            int use_nt = (ld % 32 == 0) && ((uintptr_t)d_dist % 128 == 0);
-            if (const char* en = getenv("SFMHIP_EXP_NT")) use_nt = atoi(en);
-            const dim3 g2(query->rows_pad / 128, ceil_div(train->rows_pad / 32, tpw));
-#define DM2_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_v2_kernel<K>, g2, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
-                                         train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, tpw, d_dist, ld, vec_ok, use_nt)
-            if (ks == 1) DM2_LAUNCH(1); else if (ks == 2) DM2_LAUNCH(2); else DM2_LAUNCH(4);
-#undef DM2_LAUNCH
-            SFM_HIP_TRY(ctx, hipGetLastError());
-            return SFMHIP_OK;
-        }
 #define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
                                         train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok, exp_mode)
         if (ks == 1) DM_LAUNCH(1); else if (ks == 2) DM_LAUNCH(2); else DM_LAUNCH(4);
