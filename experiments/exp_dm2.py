@@ -16,7 +16,7 @@ def run(ld, env):
     for _ in range(20): ctx.l2_distance_matrix_dev(qs, ts, out)
     e1.record(st); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 20
-variants = [("nt stores", {}), ("plain stores", {"SFMHIP_EXP_DISTMAT": "8"})]
+variants = [("plain stores", {}), ("nt stores", {"SFMHIP_EXP_DISTMAT": "8"})]
 res = {v[0]: {10000: [], 10112: []} for v in variants}
 for rnd in range(3):
     for name, env in variants:
