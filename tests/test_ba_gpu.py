@@ -210,3 +210,28 @@ def test_bundle_adjustment_wrapper_in_place(ctx, capsys):
     assert "Bundle Adjustment statistics (approximated RMSE):" in out and " #views: 6" in out
     assert s["final_cost"] < s["initial_cost"] and not np.array_equal(pts, sc["pts0"])
     assert np.array_equal(ext[0], sc["ext0"][0])
+
+
+def test_non_chain_tracks_take_the_dense_solver_and_match_oracle(ctx):
+    """Tracks through arbitrary (non-consecutive) cameras: the reduced system is not block-banded, the nested-dissection
+    plan does not apply and the dense blocked Cholesky fallback runs.  Same parity bars as the chain case."""
+    rng = np.random.default_rng(17)
+    sc = synth.ba_scene(40, 3000)
+    # re-draw each point's cameras at random (keeping the number of views), re-project with the true parameters + noise
+    L = np.bincount(sc["obs_pt"], minlength=sc["n_pt"])
+    obs_pt = np.repeat(np.arange(sc["n_pt"]), L)
+    obs_cam = np.concatenate([rng.choice(sc["n_cam"], l, replace=False) for l in L])
+    uv = synth.project(sc["K_true"], sc["ext_true"][obs_cam], sc["pts_true"][obs_pt]) + 0.5 * rng.standard_normal((obs_pt.size, 2))
+    order = np.lexsort((obs_pt, obs_cam))
+    args = (sc["K0"], sc["ext0"], sc["pts0"], obs_cam[order].astype(np.int32), obs_pt[order].astype(np.int32), np.ascontiguousarray(uv[order]))
+    pb = ctx.ba_create(*args)
+    S, rhs, cost = pb.reduced_system(1e4)
+    So, rhso, costo = orc.ba_reduced_system(*args, 1e4)
+    assert abs(cost - costo) <= 1e-12 * costo and _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9
+    assert (np.abs(So) > 0).mean() > 0.5                        # really dense
+    s = pb.iterate(6)
+    Ko, exto, ptso, so, tr = orc.ba_solve(*args, force_iterations=6)
+    assert s["successful_steps"] == so["successful_steps"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    K, ext, pts = pb.params()
+    assert np.abs(ext - exto).max() <= 1e-7 and np.abs(pts - ptso).max() <= 1e-6
