@@ -155,7 +155,7 @@ def main():
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
     cpu = None
-    if not args.no_cpu_baseline and rank == 0:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:      # reported at N=1 only
         import oracle as orc
         cores = args.cpu_threads if args.cpu_threads > 0 else min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
         orc.set_num_threads(cores)
