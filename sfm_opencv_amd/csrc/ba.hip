@@ -339,10 +339,10 @@ static int enqueue_solve(sfmhip_ba* h)
                 std::vector<long long> hs(16 * (size_t)nb);
                 (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 for (int k = 0; k < nb; ++k) {
-                    fprintf(stderr, "[stamps] panel %3d:", k);
-                    for (int i = 1; i <= 6; ++i) fprintf(stderr, " %7lld", hs[16 * k + i] - hs[16 * k + i - 1]);
-                    fprintf(stderr, " | prefetch %lld chol %lld", hs[16 * k + 7] - hs[16 * k + 1], hs[16 * k + 2] - hs[16 * k + 7]);
-                    fprintf(stderr, "   (load+sync | prefetch..chol | sync | trsm+sync | trailing | rhs+sync) cycles\n");
+                    fprintf(stderr, "[stamps] panel %3d: stage %6lld | solve %6lld | next pivot %6lld | factor (wave 0) %6lld | join %6lld   cycles\n", k,
+                            hs[16 * k + 1] - hs[16 * k + 0], hs[16 * k + 4] - hs[16 * k + 1], hs[16 * k + 5] - hs[16 * k + 4],
+                            hs[16 * k + 2] - hs[16 * k + 5], hs[16 * k + 6] - hs[16 * k + 2]);
+                    if (k + 1 < nb) fprintf(stderr, "[stamps]            to the next panel's start: %lld\n", hs[16 * (k + 1)] - hs[16 * k + 6]);
                 }
             }
         }

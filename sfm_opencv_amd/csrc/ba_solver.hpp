@@ -63,8 +63,7 @@ struct DiagLds {
 struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
-    double Dn[SNB][SLD];                // next panel's diagonal block, handed over through LDS by the trailing update
-    int Rows[SRMAX];
+    int Rows2[2][SRMAX];                // block rows of the current / next panel (double-buffered by panel parity)
     int Pi[SRMAX * (SRMAX + 1) / 2], Pj[SRMAX * (SRMAX + 1) / 2];     // block-pair list of the trailing update
 };
 
@@ -180,75 +179,77 @@ template <bool HAS_TOP>
 __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict__ A, int ld, int k0, int k1, const SolverPlan pl,
                                                double* __restrict__ rhs, double* __restrict__ topA, double* __restrict__ toprhs)
 {
+    // Look-ahead schedule.  Per panel k (entering with L_kk and its inverse in s.D / s.W, every earlier update visible):
+    //   1. all waves stage the panel's row blocks (global -> s.B), write L_kk out                          | lds barrier
+    //   2. all waves: panel solve  X = B (L_kk^-1)'  on the fp64 MFMA -> s.B and global                   | lds barrier
+    //   3. all waves: the NEXT pivot block: its trailing-update tiles first (pair (k+1,k+1), one 16x16 tile per
+    //      wave, result to global and to s.D), or a plain load if this panel does not touch it            | lds barrier
+    //   4. wave 0 factors pivot block k+1 (the long dependent chain of the whole solve) WHILE waves 1..3 run the rest
+    //      of panel k's trailing update and its right-hand-side update                                    | full barrier
+    // so the factorisation (12.7k cycles) no longer adds to the trailing update, the rhs update and the prefetches
+    // (11k cycles together): measured per panel 29.6k -> see profiles/README.md.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tid >> 5, c = tid & 31;
     const int ntop = (pl.nb - pl.top_blk) * SNB;
     bool ok = true;
-    bool diag_in_lds = false;            // the previous panel's trailing update left this panel's diagonal block in s.Dn
-    constexpr int TT = 16;               // trailing tiles per wave whose old values are prefetched at the top of the panel
+    constexpr int TT = 16;               // trailing tiles per wave whose old values are requested together
     const int li = lane & 15, lk = lane >> 4;
+#define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    if (k0 >= k1) return true;
+    // prologue: first pivot block, and the first panel's block-row list
+    { const int q0 = pl.prow_start[k0], Rq = pl.prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows2[k0 & 1][tid] = pl.prow[q0 + tid]; }
+    for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k0 * SNB + r) * ld + k0 * SNB + c];
+    __syncthreads();
+    if (wave == 0 && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
+    __syncthreads();
     for (int k = k0; k < k1; ++k) {
         const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
         const int npairs = R * (R + 1) / 2, ntiles = npairs * 4;
-#define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+        const bool has_next = k + 1 < k1;
+        const bool next_diag = has_next && R > 0 && pl.prow[p0] == k + 1;         // this panel updates the next pivot block (uniform scalar load)
         STAMP(0);
-        if (tid < R) s.Rows[tid] = pl.prow[p0 + tid];
+        int* Rows = s.Rows2[k & 1];       // written one panel ago (before the full barrier): no dependent index load in front of the staging
+        if (has_next) { const int q0 = pl.prow_start[k + 1], Rq = pl.prow_start[k + 2] - q0; if (tid < Rq) s.Rows2[(k + 1) & 1][tid] = pl.prow[q0 + tid]; }
         if (tid < npairs) { int qi = 0, rem = tid; while (rem > qi) { rem -= qi + 1; ++qi; } s.Pi[tid] = qi; s.Pj[tid] = rem; }
-        if (diag_in_lds) { for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = s.Dn[r][c]; }
-        else { for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k * SNB + r) * ld + k * SNB + c]; }
-        __syncthreads();
-        STAMP(1);
-        // request the old values of this wave's first TT trailing-update tiles now: their latency hides behind the
-        // diagonal factorisation and the panel solve
-        v4d old[TT];
+        // requests whose latency hides behind the staging and the panel solve: this wave's tile of the next pivot block
+        // and the right-hand-side entries waves 1..3 update in step 4
+        v4d old0 = { 0.0, 0.0, 0.0, 0.0 };
+        if (next_diag) {
+            const double* src = A + (size_t)((k + 1) * SNB + 16 * (wave >> 1) + lk) * ld + (k + 1) * SNB + 16 * (wave & 1) + li;
 #pragma unroll
-        for (int i = 0; i < TT; ++i) {
-            const int T = wave + 4 * i;
-            if (T < ntiles && !(pl.dbg & 4)) {
-                const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
-                const int bi = s.Rows[s.Pi[pr]], bjb = s.Rows[s.Pj[pr]];
-                const double* src; int dld;
-                if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
-                else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
-                src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+            for (int g = 0; g < 4; ++g) old0[g] = src[(size_t)(4 * g) * ld];
+        }
+        double rhs_old[2] = { 0.0, 0.0 };
 #pragma unroll
-                for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid - 64 + u * (STHREADS - 64);
+            if (wave > 0 && t < R * SNB) {
+                const int bi = Rows[t >> 5];
+                rhs_old[u] = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (t & 31)] : rhs[bi * SNB + (t & 31)];
             }
         }
-        // ... and of the right-hand-side entries this thread updates at the end of the panel
-        double rhs_old = 0.0;
-        if (tid < R * SNB) {
-            const int bi = s.Rows[tid >> 5];
-            rhs_old = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (tid & 31)] : rhs[bi * SNB + (tid & 31)];
-        }
-        STAMP(7);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above: mixed into the factorisation it cost 20k cycles per panel
-        // wave 0 factors the diagonal block while waves 1.. stage the panel's row blocks and the rhs row
-        if (wave > 0) {
-            // batches of 8 loads in flight per thread (a plain load->store loop pays one L2 round trip per element)
+        // 1. stage the row blocks (batches of 8 loads in flight per thread) and the rhs row; L_kk to global
+        {
             const int total = R * SNB * SNB;
-            for (int e0 = tid - 64; e0 < total && !(pl.dbg & 8); e0 += 8 * (STHREADS - 64)) {
-                double tmp[8];
+            for (int e0 = tid; e0 < total && !(pl.dbg & 8); e0 += 16 * STHREADS) {      // <= 4 row blocks: one round trip
+                double tmp[16];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int e = e0 + i * (STHREADS - 64);
-                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; tmp[i] = A[(size_t)(s.Rows[q] * SNB + rr) * ld + k * SNB + cc]; }
+                for (int i = 0; i < 16; ++i) {
+                    const int e = e0 + i * STHREADS;
+                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; tmp[i] = A[(size_t)(Rows[q] * SNB + rr) * ld + k * SNB + cc]; }
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int e = e0 + i * (STHREADS - 64);
+                for (int i = 0; i < 16; ++i) {
+                    const int e = e0 + i * STHREADS;
                     if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; s.B[q * SNB + rr][cc] = tmp[i]; }
                 }
             }
-            if (wave == 1 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
-        } else {
-            if (!(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
-            STAMP(2);
+            if (wave == 3 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
+            for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
         }
-        lds_barrier();                      // staged rows, L_kk and its inverse: all in LDS
-        STAMP(3);
-        for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
-        // panel rows x L^-T = B (L^-1)' on the fp64 MFMA: one 16-row tile per wave at a time, both 16-column halves
+        lds_barrier();
+        STAMP(1);
+        // 2. panel rows x L^-T = B (L^-1)' on the fp64 MFMA: one 16-row tile per wave at a time, both 16-column halves
         // (columns < 16 only see k < 16: L^-1 is lower triangular).  The tile's operand rows are in registers before
         // the results overwrite them; tiles of different waves touch disjoint rows.
         const int nrows = R * SNB + 1;
@@ -266,40 +267,61 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 const int t = 16 * rt + lk + 4 * g;
                 if (t < nrows) {
                     s.B[t][li] = x0[g]; s.B[t][16 + li] = x1[g];
-                    double* gp = (t < R * SNB) ? A + (size_t)(s.Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB : rhs + k * SNB;
+                    double* gp = (t < R * SNB) ? A + (size_t)(Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB : rhs + k * SNB;
                     gp[li] = x0[g]; gp[16 + li] = x1[g];
                 }
             }
         }
-        lds_barrier();                      // the solved rows went to LDS; their global copies are not read again in this kernel
+        lds_barrier();                      // the solved rows are in LDS; their global copies are not read again in this kernel
         STAMP(4);
-        // trailing update: A_ij -= L_ik L_jk' for the panel's block pairs (fp64 MFMA 16x16x4: each 32x32 block pair is
-        // four 16x16 tiles x 8 k-steps), rhs_i -= L_ik z_k.  Tiles are dealt round-robin to the 4 waves; the old values
-        // of a whole chunk of target tiles are requested first (one memory latency per chunk, not per tile).
-        // Operand / result maps of v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-        // D[row = (l>>4) + 4*reg][col = l&15].
-        {
-            const bool next_diag = R > 0 && s.Rows[0] == k + 1 && k + 1 < k1;
-            for (int base = wave; base < ntiles && !(pl.dbg & 4); base += 4 * TT) {
-                if (base != wave) {          // beyond the prefetched chunk (wide panels only)
+        // 3. the next pivot block into s.D.  Operand / result maps of v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4],
+        //    B[k = l>>4][j = l&15], D[row = (l>>4) + 4*reg][col = l&15].
+        if (has_next && !(pl.dbg & 4)) {
+            if (next_diag) {                // pair 0 = (Rows[0], Rows[0]) = (k+1, k+1): tile (tr, tc) = (wave >> 1, wave & 1)
+                const int tr = wave >> 1, tc = wave & 1;
+                v4d acc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-                    for (int i = 0; i < TT; ++i) {
-                        const int T = base + 4 * i;
-                        if (T < ntiles) {
-                            const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
-                            const int bi = s.Rows[s.Pi[pr]], bjb = s.Rows[s.Pj[pr]];
-                            const double* src; int dld;
-                            if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
-                            else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
-                            src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+                for (int kk = 0; kk < 8; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s.B[16 * tr + li][4 * kk + lk], s.B[16 * tc + li][4 * kk + lk], acc, 0, 0, 0);
+                double* dst = A + (size_t)((k + 1) * SNB + 16 * tr + lk) * ld + (k + 1) * SNB + 16 * tc + li;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    const double v = old0[g] - acc[g];
+                    dst[(size_t)(4 * g) * ld] = v;
+                    s.D[16 * tr + lk + 4 * g][16 * tc + li] = v;
+                }
+            } else {
+                for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)((k + 1) * SNB + r) * ld + (k + 1) * SNB + c];
+            }
+        }
+        lds_barrier();
+        STAMP(5);
+        // 4. wave 0: factor pivot block k+1; waves 1..3: the rest of the trailing update  A_ij -= L_ik L_jk'  (tiles dealt
+        //    round-robin, old values of a chunk of target tiles requested first) and  rhs_i -= L_ik z_k.
+        if (wave == 0) {
+            if (has_next && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
+            STAMP(2);
+        } else if (!(pl.dbg & 4)) {
+            const int t_first = next_diag ? 4 : 0, w3 = wave - 1;
+            for (int base = t_first + w3; base < ntiles; base += 3 * TT) {
+                v4d old[TT];
+#pragma unroll
+                for (int i = 0; i < TT; ++i) {
+                    const int T = base + 3 * i;
+                    if (T < ntiles) {
+                        const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+                        const int bi = Rows[s.Pi[pr]], bjb = Rows[s.Pj[pr]];
+                        const double* src; int dld;
+                        if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+                        else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
+                        src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < TT; ++i) {
-                    const int T = base + 4 * i;
+                    const int T = base + 3 * i;
                     if (T < ntiles) {
                         const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
                         const int qi = s.Pi[pr], qj = s.Pj[pr];
@@ -308,34 +330,33 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                         for (int kk = 0; kk < 8; ++kk)
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s.B[qi * SNB + 16 * tr + li][4 * kk + lk],
                                                                        s.B[qj * SNB + 16 * tc + li][4 * kk + lk], acc, 0, 0, 0);
-                        const int bi = s.Rows[qi], bjb = s.Rows[qj];
+                        const int bi = Rows[qi], bjb = Rows[qj];
                         double* dst; int dld;
                         if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
                         else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
                         dst += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const double v = old[i][g] - acc[g];
-                            dst[(size_t)(4 * g) * dld] = v;
-                            if (next_diag && pr == 0) s.Dn[16 * tr + lk + 4 * g][16 * tc + li] = v;     // pair 0 = (Rows[0], Rows[0])
-                        }
+                        for (int g = 0; g < 4; ++g) dst[(size_t)(4 * g) * dld] = old[i][g] - acc[g];
                     }
                 }
             }
-            diag_in_lds = next_diag && !(pl.dbg & 4);
-        }
-        STAMP(5);
-        if (tid < R * SNB) {                 // R <= SRMAX = STHREADS / 32: one entry per thread
-            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tid - 64 + u * (STHREADS - 64);
+                if (t < R * SNB) {
+                    double v = 0.0;
 #pragma unroll 8
-            for (int m = 0; m < SNB; ++m) v += s.B[tid][m] * s.B[R * SNB][m];
-            const int bi = s.Rows[tid >> 5];
-            if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (tid & 31)] = rhs_old - v;
-            else rhs[bi * SNB + (tid & 31)] = rhs_old - v;
+                    for (int m = 0; m < SNB; ++m) v += s.B[t][m] * s.B[R * SNB][m];
+                    const int bi = Rows[t >> 5];
+                    if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] = rhs_old[u] - v;
+                    else rhs[bi * SNB + (t & 31)] = rhs_old[u] - v;
+                }
+            }
         }
-        __syncthreads();
+        __syncthreads();                    // full: the next panel stages from what this one wrote to global
         STAMP(6);
     }
+#undef STAMP
     return ok;
 }
 
