@@ -181,7 +181,7 @@ struct sfmhip_ba {
     std::vector<int> pt_slot;                 // caller's point index -> slot in the HBM arrays (points sorted by camera set)
     int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
     double* d_topbuf = nullptr; size_t topbuf_count = 0;
-    int* d_sblk = nullptr; int n_sblk = 0; double* d_pack = nullptr; size_t pack_cap = 0;     // packed all-reduce message
+    int* d_sblk = nullptr; int n_sblk = 0; size_t sblk_cap = 0; double* d_pack = nullptr; size_t pack_cap = 0;     // packed all-reduce message
     double* d_ouv = nullptr;
     // work
     double *d_scale_c = nullptr, *d_scale_p = nullptr, *d_Vinv = nullptr, *d_bp = nullptr, *d_WK = nullptr, *d_colsq_p = nullptr;
@@ -506,7 +506,8 @@ static int build_solver_plan(sfmhip_ba* h)
         h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;
         h->n_sblk = (int)sblk.size() / 2;
         {
-            int rc = dalloc(h, &h->d_sblk, sblk.size()); if (rc) return rc;
+            int rc = SFMHIP_OK;
+            if (sblk.size() > h->sblk_cap) { rc = dalloc(h, &h->d_sblk, sblk.size()); if (rc) return rc; h->sblk_cap = sblk.size(); }     // re-planning (set_allreduce, reset) reuses it
             SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_sblk, sblk.data(), sblk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             const size_t need = (size_t)h->n_sblk * NB * NB + (h->msg_count - (size_t)h->npad * h->npad);
             if (need > h->pack_cap) { rc = dalloc(h, &h->d_pack, need); if (rc) return rc; h->pack_cap = need; }
