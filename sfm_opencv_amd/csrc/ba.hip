@@ -200,6 +200,7 @@ struct sfmhip_ba {
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // second stream: the Schur pair kernel runs beside the camera kernel
     hipEvent_t evb[2][5] = {};          // per build parity: [start, camera kernel begin/end, pair kernel begin/end]
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
+    bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
@@ -264,8 +265,11 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     BADev P = make_dev(h, radius, at_candidate);       // the point blocks are damped with the radius while they are built
     hipEvent_t* tv = nullptr;
     if (timed) { h->build_parity ^= 1; tv = h->evb[h->build_parity]; (void)hipEventRecord(tv[0], st); }
-    SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
-    SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
+    if (!h->cleared) {
+        SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
+        SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
+    }
+    h->cleared = false;
     hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, at_candidate ? h->d_extc : h->d_ext, h->nc,
                        at_candidate ? h->d_campre_c : h->d_campre);
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
@@ -600,6 +604,12 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 6, h->d_cam2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 8, h->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
+        // the next build's zero-fills do not depend on the decision: run them while the host waits for the scalars
+        if (!h->ar_fn) {
+            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
+            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
+            h->cleared = true;
+        }
         // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
         // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
         bool speculated = false;
@@ -821,7 +831,7 @@ int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, in
 {
     if (!h || world < 1 || world > 64 || rank < 0 || rank >= world) return SFMHIP_E_ARG;
     h->ar_fn = fn; h->ar_user = user; h->rank = rank; h->world = world;
-    h->started = false; h->built = false;
+    h->started = false; h->built = false; h->cleared = false;
     return SFMHIP_OK;
 }
 
@@ -832,7 +842,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_K, h->d_K0, 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ext, h->d_ext0, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (h->np) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts, h->d_pts0, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    h->started = false; h->built = false;
+    h->started = false; h->built = false; h->cleared = false;
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     return SFMHIP_OK;
 }
@@ -841,7 +851,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
-    h->started = false; h->built = false;
+    h->started = false; h->built = false; h->cleared = false;
     const int rc = ba_loop(h, h->o.max_num_iterations, false);
     fill_summary(h, summary, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;
