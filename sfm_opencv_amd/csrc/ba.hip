@@ -199,6 +199,8 @@ struct sfmhip_ba {
     hipEvent_t ev[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // second stream: the Schur pair kernel runs beside the camera kernel
     hipEvent_t evb[2][5] = {};          // per build parity: [start, camera kernel begin/end, pair kernel begin/end]
+    hipEvent_t evi[2][5] = {};          // per iteration parity: [damped, solved, back-substituted, forward kernel begin/end]
+    int iter_parity = 0, pending_build = -1, pending_iter = -1;       // timings not yet read (read off the decision path)
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
@@ -355,9 +357,9 @@ static int enqueue_solve(sfmhip_ba* h)
             hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, rhs_rw, h->d_y, h->d_err);
         } else {
             SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
-            (void)hipEventRecord(h->ev[8], st);
+            (void)hipEventRecord(h->evi[h->iter_parity][3], st);
             hipLaunchKernelGGL(chol_nd_forward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_topbuf, h->d_err);
-            (void)hipEventRecord(h->ev[9], st);
+            (void)hipEventRecord(h->evi[h->iter_parity][4], st);
             hipLaunchKernelGGL(chol_nd_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->nseg, rhs_rw, h->d_topbuf, h->d_y, h->d_err);
             hipLaunchKernelGGL(chol_nd_backward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_y);
         }
@@ -570,6 +572,20 @@ static int ba_start(sfmhip_ba* h)
     return SFMHIP_OK;
 }
 
+// phase / kernel timings of an iteration whose events have completed (kept off the accept/reject path)
+static void read_pending_timing(sfmhip_ba* h)
+{
+    if (h->pending_build < 0) return;
+    hipEvent_t* tb = h->evb[h->pending_build]; hipEvent_t* ti = h->evi[h->pending_iter];
+    float a = 0, b = 0, c = 0, k1 = 0, k2 = 0, k3 = 0;
+    (void)hipEventElapsedTime(&a, tb[0], ti[0]); (void)hipEventElapsedTime(&b, ti[0], ti[1]); (void)hipEventElapsedTime(&c, ti[1], ti[2]);
+    (void)hipEventElapsedTime(&k1, tb[1], tb[2]); (void)hipEventElapsedTime(&k2, tb[3], tb[4]);
+    if (h->use_sparse && h->nseg > 1) (void)hipEventElapsedTime(&k3, ti[3], ti[4]);
+    h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c;
+    h->phase_acc[4] += k1; h->phase_acc[5] += k2; h->phase_acc[6] += k3; h->phase_cnt++;
+    h->pending_build = h->pending_iter = -1;
+}
+
 // the LM loop.  forced: run exactly max_it more iterations, tolerance checks disabled.
 static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
 {
@@ -592,13 +608,15 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         int rc = SFMHIP_OK;
         if (!h->built) { rc = enqueue_build(h, h->radius, false, true); if (rc) return rc; }
         const int par = h->build_parity;            // events of the build this iteration consumes
+        h->iter_parity ^= 1;
+        hipEvent_t* ti = h->evi[h->iter_parity];
         h->built = false;                           // damping and the in-place factorisation consume it
         rc = enqueue_damp(h, h->radius); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev[1], st));
+        SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
         rc = enqueue_solve(h); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev[2], st));
+        SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
         rc = enqueue_back(h, h->radius); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev[3], st));
+        SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal, d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 2, h->d_back4, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 6, h->d_cam2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -615,16 +633,9 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         bool speculated = false;
         const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
         if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
+        read_pending_timing(h);                     // the PREVIOUS iteration's events, while the GPU works on this one
+        h->pending_build = par; h->pending_iter = h->iter_parity;
         SFM_HIP_TRY(ctx, hipEventSynchronize(h->ev_scal));
-        {
-            float a = 0, b = 0, c = 0, k1 = 0, k2 = 0, k3 = 0;
-            (void)hipEventElapsedTime(&a, h->evb[par][0], h->ev[1]); (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-            (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-            (void)hipEventElapsedTime(&k1, h->evb[par][1], h->evb[par][2]); (void)hipEventElapsedTime(&k2, h->evb[par][3], h->evb[par][4]);
-            if (h->use_sparse && h->nseg > 1) (void)hipEventElapsedTime(&k3, h->ev[8], h->ev[9]);
-            h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c;
-            h->phase_acc[4] += k1; h->phase_acc[5] += k2; h->phase_acc[6] += k3; h->phase_cnt++;
-        }
         const double cost = h->h_scal[0], gmax = h->h_scal[1], mcc = h->h_scal[2], cand_raw = h->h_scal[3];
         const double dn = h->h_scal[4] + h->h_scal[6], xn = h->h_scal[5] + h->h_scal[7];
         int err = 0; memcpy(&err, h->h_scal + 8, sizeof(int));
@@ -661,6 +672,8 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (o.verbose)
             printf("[sfmhip_ba] it %d cost %.12e gmax %.3e radius %.3e %s\n", h->iter, h->x_cost, gmax, h->radius, accepted ? "ok" : "rejected");
     }
+    (void)hipStreamSynchronize(st);
+    read_pending_timing(h);
     return SFMHIP_OK;
 }
 
@@ -703,6 +716,7 @@ void sfmhip_ba_destroy(sfmhip_ba* h)
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     for (auto& pr : h->evb) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
+    for (auto& pr : h->evi) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -819,6 +833,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     if (hipHostMalloc((void**)&h->h_scal, 16 * sizeof(double)) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipHostMalloc"; return SFMHIP_E_HIP; }
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evb) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
+    for (auto& pr : h->evi) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     if (hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "auxiliary stream"; return SFMHIP_E_HIP; }
