@@ -675,59 +675,116 @@ __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __rest
 // model cost change -sum m.(r + m/2) with m = J step, candidate cost at (Kc, extc, ptsc).
 // part_back[block][4] = { model_cost_change, candidate_cost, |delta_p|^2, |x_cand,p|^2 }
 // ------------------------------------------------------------------------------------------------
+#define BACK_NCL 24       // cameras of a block's points staged in LDS (points are stored sorted by camera set: a block of 256
+                          // consecutive points sees a handful of neighbouring cameras); wider blocks read the cameras from global
+#define BACK_REC 92       // doubles per staged camera: R/dR (36) | t (3) | candidate R/dR (36) | candidate t (3) | scale (6) | y (6) | pad
+
+struct BackCam { const double *pre, *t, *pre_c, *t_c, *sc, *y; };     // one camera's inputs of K_back (LDS record or global arrays)
+
+// body of K_back for one point; cam_at(c) -> BackCam
+template <typename CamAt>
+__device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_at, double acc[4])
+{
+    const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
+    const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
+    double t[3] = { P.bp[3 * (size_t)p], P.bp[3 * (size_t)p + 1], P.bp[3 * (size_t)p + 2] };
+    double Vi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
+    const int s0 = P.pt_start[p], s1 = P.pt_start[p + 1];
+    const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
+    double yK[4] = { 0, 0, 0, 0 };
+    if (!P.fixK) { yK[0] = P.y[P.koff]; yK[1] = P.y[P.koff + 1]; yK[2] = P.y[P.koff + 2]; yK[3] = P.y[P.koff + 3]; }
+    for (int k = s0; k < s1; ++k) {
+        const int c = P.ocam[k];
+        const bool free_cam = cam_off(P, c) >= 0;
+        const BackCam rec = cam_at(c);
+        ObsLin o;
+        obs_linearize(P.K, rec.pre, rec.t, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, free_cam ? rec.sc : nullptr, sp, o);
+        double e0 = 0.0, e1 = 0.0;
+        if (free_cam)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const double yy = rec.y[j]; e0 += o.Ec[0][j] * yy; e1 += o.Ec[1][j] * yy; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e0 += o.EK[0][j] * yK[j]; e1 += o.EK[1][j] * yK[j]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[j] -= o.F[0][j] * e0 + o.F[1][j] * e1;
+    }
+    double yp[3];
+    symv3(Vi, t, yp);
+    const double d[3] = { -yp[0] * sp[0], -yp[1] * sp[1], -yp[2] * sp[2] };
+    const double Xc[3] = { X[0] + d[0], X[1] + d[1], X[2] + d[2] };
+    P.ptsc[3 * (size_t)p] = Xc[0]; P.ptsc[3 * (size_t)p + 1] = Xc[1]; P.ptsc[3 * (size_t)p + 2] = Xc[2];
+    acc[2] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    acc[3] = Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+    for (int k = s0; k < s1; ++k) {
+        const int c = P.ocam[k];
+        const bool free_cam = cam_off(P, c) >= 0;
+        const BackCam rec = cam_at(c);
+        ObsLin o;
+        obs_linearize(P.K, rec.pre, rec.t, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, free_cam ? rec.sc : nullptr, sp, o);
+        double m0 = 0.0, m1 = 0.0;
+        if (free_cam)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const double yy = rec.y[j]; m0 -= o.Ec[0][j] * yy; m1 -= o.Ec[1][j] * yy; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m0 -= o.EK[0][j] * yK[j]; m1 -= o.EK[1][j] * yK[j]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { m0 -= o.F[0][j] * yp[j]; m1 -= o.F[1][j] * yp[j]; }
+        acc[0] -= m0 * (o.r[0] + 0.5 * m0) + m1 * (o.r[1] + 0.5 * m1);
+        acc[1] += obs_cost(P.Kc, rec.pre_c, rec.t_c, Xc, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a);
+    }
+}
+
+// fills one camera record (BACK_REC doubles) from the global arrays
+__device__ __forceinline__ double back_rec_value(const BADev& P, int c, int f)
+{
+    if (f < 36) return P.campre[36 * (size_t)c + f];
+    if (f < 39) return P.ext[6 * c + 3 + (f - 36)];
+    if (f < 75) return P.campre_c[36 * (size_t)c + (f - 39)];
+    if (f < 78) return P.extc[6 * c + 3 + (f - 75)];
+    const int co = cam_off(P, c);
+    if (f < 84) return co >= 0 ? P.scale_c[co + (f - 78)] : 0.0;
+    if (f < 90) return co >= 0 ? P.y[co + (f - 84)] : 0.0;
+    return 0.0;
+}
+
 __global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
 {
     __shared__ double red[4][4];
+    __shared__ __attribute__((aligned(16))) double cam[BACK_NCL][BACK_REC];
+    __shared__ int crange[2][4];
     const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[4] = { 0, 0, 0, 0 };
+    // camera range of the block's points (a point's observations are stored in ascending camera order only if the caller
+    // listed them so: take min / max over all of them)
+    int cmin = INT_MAX, cmax = -1;
+    if (p < P.np) for (int k = P.pt_start[p]; k < P.pt_start[p + 1]; ++k) { const int c = P.ocam[k]; cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int a = __shfl_xor(cmin, off), b = __shfl_xor(cmax, off); cmin = a < cmin ? a : cmin; cmax = b > cmax ? b : cmax; }
+    if (lane == 0) { crange[0][wave] = cmin; crange[1][wave] = cmax; }
+    __syncthreads();
+    cmin = min(min(crange[0][0], crange[0][1]), min(crange[0][2], crange[0][3]));
+    cmax = max(max(crange[1][0], crange[1][1]), max(crange[1][2], crange[1][3]));
+    const bool staged = cmax >= cmin && cmax - cmin < BACK_NCL;          // block-uniform
+    if (staged) {
+        const int n = (cmax - cmin + 1) * BACK_REC;
+        for (int e = threadIdx.x; e < n; e += 256) cam[e / BACK_REC][e % BACK_REC] = back_rec_value(P, cmin + e / BACK_REC, e % BACK_REC);
+    }
+    __syncthreads();
     if (p < P.np) {
-        const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
-        const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
-        double t[3] = { P.bp[3 * (size_t)p], P.bp[3 * (size_t)p + 1], P.bp[3 * (size_t)p + 2] };
-        double Vi[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
-        const int s0 = P.pt_start[p], s1 = P.pt_start[p + 1];
-        const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
-        double yK[4] = { 0, 0, 0, 0 };
-        if (!P.fixK) { yK[0] = P.y[P.koff]; yK[1] = P.y[P.koff + 1]; yK[2] = P.y[P.koff + 2]; yK[3] = P.y[P.koff + 3]; }
-        for (int k = s0; k < s1; ++k) {
-            const int c = P.ocam[k], co = cam_off(P, c);
-            ObsLin o;
-            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
-            double e0 = 0.0, e1 = 0.0;
-            if (co >= 0)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { const double yy = P.y[co + j]; e0 += o.Ec[0][j] * yy; e1 += o.Ec[1][j] * yy; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { e0 += o.EK[0][j] * yK[j]; e1 += o.EK[1][j] * yK[j]; }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) t[j] -= o.F[0][j] * e0 + o.F[1][j] * e1;
-        }
-        double yp[3];
-        symv3(Vi, t, yp);
-        const double d[3] = { -yp[0] * sp[0], -yp[1] * sp[1], -yp[2] * sp[2] };
-        const double Xc[3] = { X[0] + d[0], X[1] + d[1], X[2] + d[2] };
-        P.ptsc[3 * (size_t)p] = Xc[0]; P.ptsc[3 * (size_t)p + 1] = Xc[1]; P.ptsc[3 * (size_t)p + 2] = Xc[2];
-        acc[2] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-        acc[3] = Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
-        for (int k = s0; k < s1; ++k) {
-            const int c = P.ocam[k], co = cam_off(P, c);
-            ObsLin o;
-            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, co < 0 ? nullptr : P.scale_c + co, sp, o);
-            double m0 = 0.0, m1 = 0.0;
-            if (co >= 0)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { const double yy = P.y[co + j]; m0 -= o.Ec[0][j] * yy; m1 -= o.Ec[1][j] * yy; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { m0 -= o.EK[0][j] * yK[j]; m1 -= o.EK[1][j] * yK[j]; }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { m0 -= o.F[0][j] * yp[j]; m1 -= o.F[1][j] * yp[j]; }
-            acc[0] -= m0 * (o.r[0] + 0.5 * m0) + m1 * (o.r[1] + 0.5 * m1);
-            acc[1] += obs_cost(P.Kc, P.campre_c + 36 * (size_t)c, P.extc + 6 * c + 3, Xc, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a);
+        if (staged) {
+            ba_back_point(P, p, [&](int c) {
+                const double* r = &cam[c - cmin][0];
+                return BackCam{ r, r + 36, r + 39, r + 75, r + 78, r + 84 }; }, acc);
+        } else {            // the block's points span too many cameras: straight from the global arrays
+            ba_back_point(P, p, [&](int c) {
+                const int co = cam_off(P, c);
+                return BackCam{ P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, P.campre_c + 36 * (size_t)c, P.extc + 6 * c + 3,
+                                P.scale_c + (co < 0 ? 0 : co), P.y + (co < 0 ? 0 : co) }; }, acc);
         }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
     if (lane == 0)
