@@ -122,3 +122,37 @@ def test_c4_bundle_adjustment_full_size(ctx):
     assert abs(acc_c - cf) <= 1e-11 * cf
     assert np.abs(acc_S - Sf).max() <= 1e-10 * np.abs(Sf).max() and np.abs(acc_r - rf).max() <= 1e-10 * max(np.abs(rf).max(), 1e-300)
     pb.close(); pb2.close()
+
+
+def test_c4_pair_hamming2_self_match_and_oracle_slice(ctx):
+    """AKAZE-like 61-byte descriptors at the C4 per-pair size (the reference's live NORM_HAMMING2 configuration)."""
+    d = synth.akaze_descriptor_chain(2, 5000, seed=99)
+    a, b = d[0], d[1]
+    gi, gd = ctx.knn2_hamming2(a, a)
+    if np.unique(a, axis=0).shape[0] == a.shape[0]:
+        assert np.array_equal(gi[:, 0], np.arange(5000)) and not gd[:, 0].any()
+    gi1, gd1 = ctx.knn2_hamming2(a, b)
+    rows = np.random.default_rng(4).choice(5000, 400, replace=False)
+    oi, od = orc.knn2_hamming2(a[rows], b)
+    assert np.array_equal(gi1[rows], oi) and np.array_equal(gd1[rows], od)
+    # distances are counts of differing 2-bit cells: integers in [0, 244]
+    assert (gd1 == np.round(gd1)).all() and gd1.min() >= 0 and gd1.max() <= 244
+
+
+def test_kernel_timing_api_and_full_size_tracks(ctx):
+    # per-kernel timing of the matching path: two timed calls -> averaged over 2, then the counter resets
+    d = synth.sift_descriptor_chain(2, 2000, seed=5)
+    ctx.set_kernel_timing(True)
+    ctx.knn2_l2(d[0], d[1]); ctx.knn2_l2(d[0], d[1])
+    t = ctx.match_kernel_ms()
+    assert t[2] == 2 and t[0] > 0 and t[1] > 0
+    assert ctx.match_kernel_ms()[2] == 0
+    ctx.set_kernel_timing(False)
+    # N-view DLT at the C4 track count: noise-free tracks come back exactly, whatever the observation order
+    sc = synth.ba_scene(200, 300_000, noise_px=0.0, outlier_frac=0.0, perturb=False)
+    perm = np.random.default_rng(8).permutation(sc["n_obs"])
+    pts, nv = ctx.triangulate_tracks(sc["K_true"], sc["ext_true"], sc["obs_cam"][perm], sc["obs_pt"][perm], sc["obs_uv"][perm], sc["n_pt"])
+    assert np.array_equal(nv, np.bincount(sc["obs_pt"], minlength=sc["n_pt"]))
+    assert np.abs(pts - sc["pts_true"]).max() < 1e-7
+    err = ctx.reprojection_errors(sc["K_true"], sc["ext_true"], pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    assert err.max() < 1e-6
