@@ -171,7 +171,7 @@ struct sfmhip_ba {
     double *d_K0 = nullptr, *d_ext0 = nullptr, *d_pts0 = nullptr;
     double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera R and dR/dw (36 doubles), current / candidate
     // structure
-    int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_obs = nullptr;
+    int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_pt = nullptr;
     int *d_blk_cam = nullptr, *d_blk_chunk = nullptr; int4 *d_items = nullptr, *d_chunk_desc = nullptr; int nchunk = 0; double* d_part_schur = nullptr;
     int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
     std::vector<int> host_blk_cam;
@@ -182,7 +182,7 @@ struct sfmhip_ba {
     int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
     double* d_topbuf = nullptr; size_t topbuf_count = 0;
     int* d_sblk = nullptr; int n_sblk = 0; size_t sblk_cap = 0; double* d_pack = nullptr; size_t pack_cap = 0;     // packed all-reduce message
-    double* d_ouv = nullptr;
+    double *d_ouv = nullptr, *d_cam_uv = nullptr;
     // work
     double *d_scale_c = nullptr, *d_scale_p = nullptr, *d_Vinv = nullptr, *d_bp = nullptr, *d_WK = nullptr, *d_colsq_p = nullptr;
     double *d_msg = nullptr; size_t msg_count = 0;
@@ -233,7 +233,7 @@ static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = fal
     P.huber_a = h->o.huber_delta;
     P.K = h->d_K; P.ext = h->d_ext; P.pts = h->d_pts; P.Kc = h->d_Kc; P.extc = h->d_extc; P.ptsc = h->d_ptsc;
     P.pt_start = h->d_pt_start; P.ocam = h->d_ocam; P.ouv = h->d_ouv;
-    P.cam_start = h->d_cam_start; P.cam_obs = h->d_cam_obs; P.opt = h->d_opt;
+    P.cam_start = h->d_cam_start; P.cam_pt = h->d_cam_pt; P.cam_uv = h->d_cam_uv; P.opt = h->d_opt;
     P.cam_pos = h->d_cam_pos; P.posmask = h->d_posmask;
     P.campre = h->d_campre; P.campre_c = h->d_campre_c;
     P.scale_c = h->d_scale_c; P.scale_p = h->d_scale_p;
@@ -768,13 +768,19 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     for (int p = 0; p < n_pt; ++p) pt_start[p + 1] += pt_start[p];
     for (int k = 0; k < n_obs; ++k) { const int p = slot[obs_pt[k]]; perm[pt_start[p] + fill[p]++] = k; }
     for (int q = 0; q < n_obs; ++q) { const int k = perm[q]; ocam[q] = obs_cam[k]; opt[q] = slot[obs_pt[k]]; ouv[2 * (size_t)q] = obs_uv[2 * (size_t)k]; ouv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)k + 1]; }
-    std::vector<int> cam_start(n_cam + 1, 0), cam_obs(n_obs), cfill(n_cam, 0);
+    std::vector<int> cam_start(n_cam + 1, 0), cam_pt(n_obs), cfill(n_cam, 0);
+    std::vector<double> cam_uv(2 * (size_t)n_obs);
     for (int q = 0; q < n_obs; ++q) cam_start[ocam[q] + 1]++;
     for (int c = 0; c < n_cam; ++c) cam_start[c + 1] += cam_start[c];
-    for (int q = 0; q < n_obs; ++q) { const int c = ocam[q]; cam_obs[cam_start[c] + cfill[c]++] = q; }
+    for (int q = 0; q < n_obs; ++q) {           // camera-ordered copy of (point slot, pixel): the camera kernel reads it in runs
+        const int c = ocam[q], at = cam_start[c] + cfill[c]++;
+        cam_pt[at] = opt[q]; cam_uv[2 * (size_t)at] = ouv[2 * (size_t)q]; cam_uv[2 * (size_t)at + 1] = ouv[2 * (size_t)q + 1];
+    }
     int max_cam = 1;
     for (int c = 0; c < n_cam; ++c) max_cam = std::max(max_cam, cam_start[c + 1] - cam_start[c]);
-    h->cam_split = std::min(32, std::max(1, ceil_div(max_cam, 1024)));
+    int cam_wg_obs = 1024;            // observations per camera workgroup (4 per thread)
+    if (const char* e = getenv("SFMHIP_CAM_WG_OBS")) cam_wg_obs = std::max(256, atoi(e));
+    h->cam_split = std::min(32, std::max(1, ceil_div(max_cam, cam_wg_obs)));
     // camera-pair lists for the off-diagonal Schur blocks (and same-camera pairs)
     struct Item { long long key; int qi, qj; };
     std::vector<Item> items;
@@ -813,7 +819,8 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_Kc, K4, 4)); TRY_RC(dupload(h, &h->d_extc, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_ptsc, pts_s.data(), 3 * (size_t)n_pt));
     TRY_RC(dupload(h, &h->d_pt_start, pt_start.data(), pt_start.size())); TRY_RC(dupload(h, &h->d_ocam, ocam.data(), ocam.size()));
     TRY_RC(dupload(h, &h->d_opt, opt.data(), opt.size())); TRY_RC(dupload(h, &h->d_ouv, ouv.data(), ouv.size()));
-    TRY_RC(dupload(h, &h->d_cam_start, cam_start.data(), cam_start.size())); TRY_RC(dupload(h, &h->d_cam_obs, cam_obs.data(), cam_obs.size()));
+    TRY_RC(dupload(h, &h->d_cam_start, cam_start.data(), cam_start.size())); TRY_RC(dupload(h, &h->d_cam_pt, cam_pt.data(), cam_pt.size()));
+    TRY_RC(dupload(h, &h->d_cam_uv, cam_uv.data(), cam_uv.size()));
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_chunk, blk_chunk.data(), blk_chunk.size()));
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size())); TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));
     TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));

@@ -27,7 +27,7 @@ struct BADev {
     // observations ordered by point
     const int* pt_start; const int* ocam; const double* ouv;
     // per-camera lists (indices into the by-point ordering) and their points
-    const int* cam_start; const int* cam_obs; const int* opt;
+    const int* cam_start; const int* cam_pt; const double* cam_uv; const int* opt;   // cam_pt / cam_uv: point slot and pixel of each observation, in camera order
     // layout of the reduced system: position of camera c's 6 columns (-1 = constant camera), koff = intrinsics;
     // posmask[i] = 1 for a real parameter, 0 for a padding slot (segments are padded to whole 32-blocks)
     const int* cam_pos; const int* posmask;
@@ -267,6 +267,59 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+// N per-lane accumulators -> their 64-lane totals, one per lane: every step pairs accumulators (x, y), leaves the lanes
+// whose bit `off` is clear with x summed over {l, l ^ off} and the others with y, and so halves the number of live values
+// (N + N/2 + ... ~ 2N exchanges instead of 6N butterflies).  Steps 32 and 16 are one v_permlane{32,16}_swap per dword,
+// no select.  Returns the total of accumulator wave_scatter_index(lane) (garbage where that index is >= N).  The
+// summation order is fixed, so results are run-to-run identical.
+__device__ __forceinline__ void lane_swap32(double& a, double& b)
+{
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ void lane_swap16(double& a, double& b)
+{
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ int wave_scatter_index(int lane) { return (int)(__brev((unsigned)lane) >> 26); }
+
+template <int OFF, int N>
+__device__ __forceinline__ void wave_scatter_step(const double (&in)[N], double (&out)[(N + 1) / 2], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        double x = in[2 * i], y = (2 * i + 1 < N) ? in[2 * i + 1] : 0.0;
+        if (OFF == 32) { lane_swap32(x, y); out[i] = x + y; }
+        else if (OFF == 16) { lane_swap16(x, y); out[i] = x + y; }
+        else {
+            const bool up = (lane & OFF) != 0;
+            const double keep = up ? y : x, send = up ? x : y;
+            out[i] = keep + __shfl_xor(send, OFF);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ double wave_reduce_scatter(const double (&a)[N], int lane)
+{
+    static_assert(N >= 1 && N <= 64, "one accumulator per lane at most");
+    double s1[(N + 1) / 2];                     wave_scatter_step<32>(a, s1, lane);
+    double s2[((N + 1) / 2 + 1) / 2];           wave_scatter_step<16>(s1, s2, lane);
+    constexpr int N2 = ((N + 1) / 2 + 1) / 2;
+    double s3[(N2 + 1) / 2];                    wave_scatter_step<8>(s2, s3, lane);
+    constexpr int N3 = (N2 + 1) / 2;
+    double s4[(N3 + 1) / 2];                    wave_scatter_step<4>(s3, s4, lane);
+    constexpr int N4 = (N3 + 1) / 2;
+    double s5[(N4 + 1) / 2];                    wave_scatter_step<2>(s4, s5, lane);
+    constexpr int N5 = (N4 + 1) / 2;
+    double s6[(N5 + 1) / 2];                    wave_scatter_step<1>(s5, s6, lane);
+    return s6[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_pt: one thread per point.  V_p = sum F'F + D_p^2, b_p = sum F'r, WK_p = sum EK'F; stores V_p^-1, b_p, WK_p,
 // the raw squared column norms, and per-block partials of: cost, the point-eliminated intrinsic terms
@@ -336,12 +389,16 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
         acc[15] = fmax(fabs(b[0] / sp[0]), fmax(fabs(b[1] / sp[1]), fabs(b[2] / sp[2])));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        double v15[15];
 #pragma unroll
-    for (int i = 0; i < 15; ++i) acc[i] = wave_sum(acc[i]);
-    acc[15] = wave_max(acc[15]);
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) red[wave][i] = acc[i];
+        for (int i = 0; i < 15; ++i) v15[i] = acc[i];
+        const double tot = wave_reduce_scatter(v15, lane);
+        const double gm = wave_max(acc[15]);
+        const int j = wave_scatter_index(lane);
+        if (j < 15) red[wave][j] = tot;
+        if (lane == 0) red[wave][15] = gm;
+    }
     __syncthreads();
     if (threadIdx.x < 16) {
         const int i = threadIdx.x;
@@ -366,6 +423,10 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
 // diagU_c, graw_c: 39 accumulators), part 1 the camera-intrinsic ones (ScK, UKK, gK: 38).  Both re-derive the
 // linearisation; with all 77 in one thread the kernel needed 324 registers = one wave per SIMD, and PMC showed it
 // 42 % waiting on its gathers with nothing else resident to issue (140 us; the split form: see profiles/README.md).
+__host__ __device__ constexpr int cam_part_slot(int part, int j)
+{
+    return part == 0 ? (j < 21 ? j : j < 27 ? 45 + (j - 21) : 65 + (j - 27)) : (j < 24 ? 21 + j : 51 + (j - 24));
+}
 template <int PART>
 __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAMACC])
 {
@@ -381,35 +442,42 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     const double* sc = co < 0 ? nullptr : P.scale_c + co;
     const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
     for (int q = b0 + threadIdx.x; q < b1; q += 256) {
-        const int k = P.cam_obs[q], p = P.opt[k];
+        const int p = P.cam_pt[q];
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         ObsLin o;
-        obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, sc, spp, o);
+        obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.cam_uv[2 * (size_t)q], P.cam_uv[2 * (size_t)q + 1], P.huber_a, sK, sc, spp, o);
         double Vi[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
-        double W[6][3], T[6][3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) W[i][j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
-            symv3(Vi, W[i], T[i]);
-        }
+        // (Ec' F) V^-1 (F' Ec) = Ec' (F V^-1 F') Ec: the 2x2 core G F' is formed first, so the point block never
+        // expands to 6x3 per observation
+        double G[2][3];
+        symv3(Vi, o.F[0], G[0]);
+        symv3(Vi, o.F[1], G[1]);
         if (PART == 0) {
             double b[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) b[i] = P.bp[3 * (size_t)p + i];
+            // Q = I - F V^-1 F' (symmetric), N = Q Ec
+            const double q00 = 1.0 - (G[0][0] * o.F[0][0] + G[0][1] * o.F[0][1] + G[0][2] * o.F[0][2]);
+            const double q01 = -(G[0][0] * o.F[1][0] + G[0][1] * o.F[1][1] + G[0][2] * o.F[1][2]);
+            const double q11 = 1.0 - (G[1][0] * o.F[1][0] + G[1][1] * o.F[1][1] + G[1][2] * o.F[1][2]);
+            double N0[6], N1[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                N0[j] = q00 * o.Ec[0][j] + q01 * o.Ec[1][j];
+                N1[j] = q01 * o.Ec[0][j] + q11 * o.Ec[1][j];
+            }
             int a = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j)
-                    acc[a++] += o.Ec[0][i] * o.Ec[0][j] + o.Ec[1][i] * o.Ec[1][j]
-                                - (T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2]);
+                for (int j = 0; j <= i; ++j) acc[a++] += o.Ec[0][i] * N0[j] + o.Ec[1][i] * N1[j];
+            const double r0 = o.r[0] - (G[0][0] * b[0] + G[0][1] * b[1] + G[0][2] * b[2]);
+            const double r1 = o.r[1] - (G[1][0] * b[0] + G[1][1] * b[1] + G[1][2] * b[2]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                acc[45 + i] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1] - (T[i][0] * b[0] + T[i][1] * b[1] + T[i][2] * b[2]);
+            for (int i = 0; i < 6; ++i) acc[45 + i] += o.Ec[0][i] * r0 + o.Ec[1][i] * r1;
 #pragma unroll
             for (int i = 0; i < 6; ++i) acc[65 + i] += o.Ec[0][i] * o.Ec[0][i] + o.Ec[1][i] * o.Ec[1][i];
 #pragma unroll
@@ -418,13 +486,17 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
             double WK[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) WK[i] = P.WK[12 * (size_t)p + i];
+            double H0[4], H1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                H0[j] = o.EK[0][j] - (G[0][0] * WK[3 * j] + G[0][1] * WK[3 * j + 1] + G[0][2] * WK[3 * j + 2]);
+                H1[j] = o.EK[1][j] - (G[1][0] * WK[3 * j] + G[1][1] * WK[3 * j + 1] + G[1][2] * WK[3 * j + 2]);
+            }
             int a = 21;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[a++] += o.Ec[0][i] * o.EK[0][j] + o.Ec[1][i] * o.EK[1][j]
-                                - (T[i][0] * WK[3 * j] + T[i][1] * WK[3 * j + 1] + T[i][2] * WK[3 * j + 2]);
+                for (int j = 0; j < 4; ++j) acc[a++] += o.Ec[0][i] * H0[j] + o.Ec[1][i] * H1[j];
             a = 51;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -436,11 +508,13 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this part's slots: part 0 -> [0,21) u [45,51) u [65,77), part 1 -> [21,45) u [51,65)
+    constexpr int NV = (PART == 0) ? 39 : 38;
+    double v[NV];
 #pragma unroll
-    for (int i = 0; i < 77; ++i) {
-        const bool mine = (PART == 0) ? (i < 21 || (i >= 45 && i < 51) || i >= 65) : ((i >= 21 && i < 45) || (i >= 51 && i < 65));
-        if (mine) { acc[i] = wave_sum(acc[i]); if (lane == 0) red[wave][i] = acc[i]; }
-    }
+    for (int j = 0; j < NV; ++j) v[j] = acc[cam_part_slot(PART, j)];
+    const double tot = wave_reduce_scatter(v, lane);
+    const int j = wave_scatter_index(lane);
+    if (j < NV) red[wave][cam_part_slot(PART, j)] = tot;
     __syncthreads();
     if (threadIdx.x < 77) {
         const int i = threadIdx.x;
@@ -449,7 +523,7 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     }
 }
 
-__global__ __launch_bounds__(256, 2) void ba_camera_kernel(BADev P)
+__global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
 {
     __shared__ double red[4][CAMACC];
     if (blockIdx.z == 0) ba_camera_body<0>(P, red); else ba_camera_body<1>(P, red);
@@ -552,7 +626,7 @@ __global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_bloc
 // S_ab = S_ba' = -sum; a == b (one point seen twice by one camera) adds the symmetrised term onto the diagonal
 // block written by K_finalize.  chunk_desc: [ca, cb, first item, end item]; items: [obs i, obs j, point, -].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
+__global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
                                                        const int4* __restrict__ items, double* __restrict__ part)
 {
     const int lane = threadIdx.x & 63;
@@ -573,39 +647,39 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev P, const int4* __re
         double Vi[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
-        double T[6][3], W[6][3];
+        // T_i W_j' = Ec_a' (F_a V^-1 F_b') Ec_b: 2x2 core first, then 2x6, then the 6x6 outer product (126 fma against
+        // 234 for the 6x3 forms)
+        double G[2][3], Ea[2][6];
         {
             ObsLin o;
             obs_linearize(P.K, P.campre + 36 * (size_t)ca, P.ext + 6 * ca + 3, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
+            symv3(Vi, o.F[0], G[0]);
+            symv3(Vi, o.F[1], G[1]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                double w[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) w[j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
-                symv3(Vi, w, T[i]);
-            }
+            for (int i = 0; i < 6; ++i) { Ea[0][i] = o.Ec[0][i]; Ea[1][i] = o.Ec[1][i]; }
         }
+        double N0[6], N1[6];
         {
             ObsLin o;
             obs_linearize(P.K, P.campre + 36 * (size_t)cb, P.ext + 6 * cb + 3, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
+            const double m00 = G[0][0] * o.F[0][0] + G[0][1] * o.F[0][1] + G[0][2] * o.F[0][2];
+            const double m01 = G[0][0] * o.F[1][0] + G[0][1] * o.F[1][1] + G[0][2] * o.F[1][2];
+            const double m10 = G[1][0] * o.F[0][0] + G[1][1] * o.F[0][1] + G[1][2] * o.F[0][2];
+            const double m11 = G[1][0] * o.F[1][0] + G[1][1] * o.F[1][1] + G[1][2] * o.F[1][2];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) W[i][j] = o.Ec[0][i] * o.F[0][j] + o.Ec[1][i] * o.F[1][j];
+            for (int j = 0; j < 6; ++j) {
+                N0[j] = m00 * o.Ec[0][j] + m01 * o.Ec[1][j];
+                N1[j] = m10 * o.Ec[0][j] + m11 * o.Ec[1][j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] += T[i][0] * W[j][0] + T[i][1] * W[j][1] + T[i][2] * W[j][2];
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] += Ea[0][i] * N0[j] + Ea[1][i] * N1[j];
     }
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
-    // lane q < 36 keeps element q (static selection, no dynamic register indexing)
-    double mine = 0.0;
-#pragma unroll
-    for (int i = 0; i < 36; ++i)
-        if (lane == i) mine = acc[i];
-    if (lane < 36) part[36 * (size_t)chunk + lane] = mine;
+    const double tot = wave_reduce_scatter(acc, lane);
+    const int e = wave_scatter_index(lane);
+    if (e < 36) part[36 * (size_t)chunk + e] = tot;
 }
 
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
