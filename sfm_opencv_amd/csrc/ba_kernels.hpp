@@ -226,15 +226,15 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
 // symmetric 3x3 inverse through Cholesky; V = [v00 v10 v11 v20 v21 v22] (lower), same layout out.
 __device__ __forceinline__ bool inv3_spd(const double V[6], double Vi[6])
 {
+    // only the reciprocals of the Cholesky diagonal are needed: rsqrt_nr instead of sqrt + divide
     bool ok = V[0] > 0.0;
-    const double l00 = sqrt(V[0]);
-    const double l10 = V[1] / l00, l20 = V[3] / l00;
+    const double i00 = rsqrt_nr(V[0]);
+    const double l10 = V[1] * i00, l20 = V[3] * i00;
     const double d11 = V[2] - l10 * l10; ok = ok && d11 > 0.0;
-    const double l11 = sqrt(d11);
-    const double l21 = (V[4] - l20 * l10) / l11;
+    const double i11 = rsqrt_nr(d11);
+    const double l21 = (V[4] - l20 * l10) * i11;
     const double d22 = V[5] - l20 * l20 - l21 * l21; ok = ok && d22 > 0.0;
-    const double l22 = sqrt(d22);
-    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i22 = rsqrt_nr(d22);
     const double i10 = -l10 * i00 * i11;
     const double i21 = -l21 * i11 * i22;
     const double i20 = -(l20 * i00 + l21 * i10) * i22;
@@ -347,18 +347,21 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
             obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
                           P.fixK ? nullptr : P.scale_c + P.koff, nullptr, sp, o);
             cost += 0.5 * o.rho0;
-            V[0] += o.F[0][0] * o.F[0][0] + o.F[1][0] * o.F[1][0];
-            V[1] += o.F[0][1] * o.F[0][0] + o.F[1][1] * o.F[1][0];
-            V[2] += o.F[0][1] * o.F[0][1] + o.F[1][1] * o.F[1][1];
-            V[3] += o.F[0][2] * o.F[0][0] + o.F[1][2] * o.F[1][0];
-            V[4] += o.F[0][2] * o.F[0][1] + o.F[1][2] * o.F[1][1];
-            V[5] += o.F[0][2] * o.F[0][2] + o.F[1][2] * o.F[1][2];
+            // two chained fma per sum (x*y + z*w + acc would be mul, fma, add)
+#define ACC2(dst, x0, y0, x1, y1) do { dst = fma(x0, y0, dst); dst = fma(x1, y1, dst); } while (0)
+            ACC2(V[0], o.F[0][0], o.F[0][0], o.F[1][0], o.F[1][0]);
+            ACC2(V[1], o.F[0][1], o.F[0][0], o.F[1][1], o.F[1][0]);
+            ACC2(V[2], o.F[0][1], o.F[0][1], o.F[1][1], o.F[1][1]);
+            ACC2(V[3], o.F[0][2], o.F[0][0], o.F[1][2], o.F[1][0]);
+            ACC2(V[4], o.F[0][2], o.F[0][1], o.F[1][2], o.F[1][1]);
+            ACC2(V[5], o.F[0][2], o.F[0][2], o.F[1][2], o.F[1][2]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[j] += o.F[0][j] * o.r[0] + o.F[1][j] * o.r[1];
+            for (int j = 0; j < 3; ++j) ACC2(b[j], o.F[0][j], o.r[0], o.F[1][j], o.r[1]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) WK[3 * i + j] += o.EK[0][i] * o.F[0][j] + o.EK[1][i] * o.F[1][j];
+                for (int j = 0; j < 3; ++j) ACC2(WK[3 * i + j], o.EK[0][i], o.F[0][j], o.EK[1][i], o.F[1][j]);
+#undef ACC2
         }
         const double cs[3] = { V[0], V[2], V[5] };
         P.colsq_p[3 * p] = cs[0]; P.colsq_p[3 * p + 1] = cs[1]; P.colsq_p[3 * p + 2] = cs[2];
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
                 acc[q++] = T[3 * i] * WK[3 * j] + T[3 * i + 1] * WK[3 * j + 1] + T[3 * i + 2] * WK[3 * j + 2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[11 + i] = T[3 * i] * b[0] + T[3 * i + 1] * b[1] + T[3 * i + 2] * b[2];
-        acc[15] = fmax(fabs(b[0] / sp[0]), fmax(fabs(b[1] / sp[1]), fabs(b[2] / sp[2])));
+        acc[15] = fmax(fabs(b[0] * rcp_nr(sp[0])), fmax(fabs(b[1] * rcp_nr(sp[1])), fabs(b[2] * rcp_nr(sp[2]))));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
@@ -441,8 +444,11 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     int b1 = b0 + per; if (b1 > s1) b1 = s1;
     const double* sc = co < 0 ? nullptr : P.scale_c + co;
     const double* sK = P.fixK ? nullptr : P.scale_c + P.koff;
+    // the next trip's point index is fetched one trip ahead: the gathers below then start without waiting for it
+    int p_next = (b0 + (int)threadIdx.x < b1) ? P.cam_pt[b0 + threadIdx.x] : 0;
     for (int q = b0 + threadIdx.x; q < b1; q += 256) {
-        const int p = P.cam_pt[q];
+        const int p = p_next;
+        if (q + 256 < b1) p_next = P.cam_pt[q + 256];
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         ObsLin o;
@@ -473,15 +479,15 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) acc[a++] += o.Ec[0][i] * N0[j] + o.Ec[1][i] * N1[j];
+                for (int j = 0; j <= i; ++j) { acc[a] = fma(o.Ec[0][i], N0[j], acc[a]); acc[a] = fma(o.Ec[1][i], N1[j], acc[a]); ++a; }
             const double r0 = o.r[0] - (G[0][0] * b[0] + G[0][1] * b[1] + G[0][2] * b[2]);
             const double r1 = o.r[1] - (G[1][0] * b[0] + G[1][1] * b[1] + G[1][2] * b[2]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[45 + i] += o.Ec[0][i] * r0 + o.Ec[1][i] * r1;
+            for (int i = 0; i < 6; ++i) { acc[45 + i] = fma(o.Ec[0][i], r0, acc[45 + i]); acc[45 + i] = fma(o.Ec[1][i], r1, acc[45 + i]); }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[65 + i] += o.Ec[0][i] * o.Ec[0][i] + o.Ec[1][i] * o.Ec[1][i];
+            for (int i = 0; i < 6; ++i) { acc[65 + i] = fma(o.Ec[0][i], o.Ec[0][i], acc[65 + i]); acc[65 + i] = fma(o.Ec[1][i], o.Ec[1][i], acc[65 + i]); }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[71 + i] += o.Ec[0][i] * o.r[0] + o.Ec[1][i] * o.r[1];
+            for (int i = 0; i < 6; ++i) { acc[71 + i] = fma(o.Ec[0][i], o.r[0], acc[71 + i]); acc[71 + i] = fma(o.Ec[1][i], o.r[1], acc[71 + i]); }
         } else {
             double WK[12];
 #pragma unroll
@@ -496,14 +502,14 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[a++] += o.Ec[0][i] * H0[j] + o.Ec[1][i] * H1[j];
+                for (int j = 0; j < 4; ++j) { acc[a] = fma(o.Ec[0][i], H0[j], acc[a]); acc[a] = fma(o.Ec[1][i], H1[j], acc[a]); ++a; }
             a = 51;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) acc[a++] += o.EK[0][i] * o.EK[0][j] + o.EK[1][i] * o.EK[1][j];
+                for (int j = 0; j <= i; ++j) { acc[a] = fma(o.EK[0][i], o.EK[0][j], acc[a]); acc[a] = fma(o.EK[1][i], o.EK[1][j], acc[a]); ++a; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[61 + i] += o.EK[0][i] * o.r[0] + o.EK[1][i] * o.r[1];
+            for (int i = 0; i < 4; ++i) { acc[61 + i] = fma(o.EK[0][i], o.r[0], acc[61 + i]); acc[61 + i] = fma(o.EK[1][i], o.r[1], acc[61 + i]); }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -639,8 +645,10 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    int4 it_next = (s0 + lane < s1) ? items[s0 + lane] : make_int4(0, 0, 0, 0);
     for (int q = s0 + lane; q < s1; q += 64) {
-        const int4 it = items[q];
+        const int4 it = it_next;
+        if (q + 64 < s1) it_next = items[q + 64];
         const int ki = it.x, kj = it.y, p = it.z;
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] += Ea[0][i] * N0[j] + Ea[1][i] * N1[j];
+            for (int j = 0; j < 6; ++j) { acc[6 * i + j] = fma(Ea[0][i], N0[j], acc[6 * i + j]); acc[6 * i + j] = fma(Ea[1][i], N1[j], acc[6 * i + j]); }
     }
     const double tot = wave_reduce_scatter(acc, lane);
     const int e = wave_scatter_index(lane);
