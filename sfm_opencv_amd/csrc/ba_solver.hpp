@@ -23,7 +23,9 @@
 #define SNB 32
 #define SLD 33          // LDS row stride in doubles: conflict-free row and column access
 #define SRMAX 8         // max sub-diagonal blocks per panel for the single-workgroup path
-#define STHREADS 256    // 4 waves, one per SIMD: the full register file for the unrolled 32-double register rows
+#define STHREADS 512    // 8 waves, two per SIMD: wave 0 runs the pivot-block chain, the other seven share the trailing update
+#define SWAVES (STHREADS / 64)
+#define SSTAGE (4096 / STHREADS)   // staging loads in flight per thread: four 32x32 row blocks per round trip
 #define SROWS (STHREADS / 32)
 #ifndef SPW
 #define SPW 16          // panel width of the 32x32 pivot-block factorisation (columns a lane keeps in registers)
@@ -192,7 +194,9 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     const int r0 = tid >> 5, c = tid & 31;
     const int ntop = (pl.nb - pl.top_blk) * SNB;
     bool ok = true;
-    constexpr int TT = 16;               // trailing tiles per wave whose old values are requested together
+    constexpr int TT = 8;                // trailing tiles per wave whose old values are requested together
+    constexpr int NT = SWAVES - 2;       // waves that share the trailing update: all but wave 0 (pivot chain) and wave 4, which
+                                         // shares wave 0's SIMD (the chain runs 8 % slower with a busy neighbour)
     const int li = lane & 15, lk = lane >> 4;
 #define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     if (k0 >= k1) return true;
@@ -214,7 +218,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // requests whose latency hides behind the staging and the panel solve: this wave's tile of the next pivot block
         // and the right-hand-side entries waves 1..3 update in step 4
         v4d old0 = { 0.0, 0.0, 0.0, 0.0 };
-        if (next_diag) {
+        if (next_diag && wave < 4) {
             const double* src = A + (size_t)((k + 1) * SNB + 16 * (wave >> 1) + lk) * ld + (k + 1) * SNB + 16 * (wave & 1) + li;
 #pragma unroll
             for (int g = 0; g < 4; ++g) old0[g] = src[(size_t)(4 * g) * ld];
@@ -231,15 +235,15 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // 1. stage the row blocks (batches of 8 loads in flight per thread) and the rhs row; L_kk to global
         {
             const int total = R * SNB * SNB;
-            for (int e0 = tid; e0 < total && !(pl.dbg & 8); e0 += 16 * STHREADS) {      // <= 4 row blocks: one round trip
-                double tmp[16];
+            for (int e0 = tid; e0 < total && !(pl.dbg & 8); e0 += SSTAGE * STHREADS) {      // <= 4 row blocks: one round trip
+                double tmp[SSTAGE];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < SSTAGE; ++i) {
                     const int e = e0 + i * STHREADS;
                     if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; tmp[i] = A[(size_t)(Rows[q] * SNB + rr) * ld + k * SNB + cc]; }
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < SSTAGE; ++i) {
                     const int e = e0 + i * STHREADS;
                     if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; s.B[q * SNB + rr][cc] = tmp[i]; }
                 }
@@ -253,7 +257,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // (columns < 16 only see k < 16: L^-1 is lower triangular).  The tile's operand rows are in registers before
         // the results overwrite them; tiles of different waves touch disjoint rows.
         const int nrows = R * SNB + 1;
-        for (int rt = wave; rt * 16 < nrows && !(pl.dbg & 2); rt += 4) {
+        for (int rt = wave; rt * 16 < nrows && !(pl.dbg & 2); rt += SWAVES) {
             double a[8];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) a[kk] = s.B[16 * rt + li][4 * kk + lk];        // rows past nrows: stale LDS, results dropped
@@ -277,7 +281,8 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // 3. the next pivot block into s.D.  Operand / result maps of v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4],
         //    B[k = l>>4][j = l&15], D[row = (l>>4) + 4*reg][col = l&15].
         if (has_next && !(pl.dbg & 4)) {
-            if (next_diag) {                // pair 0 = (Rows[0], Rows[0]) = (k+1, k+1): tile (tr, tc) = (wave >> 1, wave & 1)
+            if (next_diag) {                // pair 0 = (Rows[0], Rows[0]) = (k+1, k+1): tile (tr, tc) = (wave >> 1, wave & 1), waves 0..3
+              if (wave < 4) {
                 const int tr = wave >> 1, tc = wave & 1;
                 v4d acc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -290,6 +295,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                     dst[(size_t)(4 * g) * ld] = v;
                     s.D[16 * tr + lk + 4 * g][16 * tc + li] = v;
                 }
+              }
             } else {
                 for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)((k + 1) * SNB + r) * ld + (k + 1) * SNB + c];
             }
@@ -302,12 +308,12 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             if (has_next && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
             STAMP(2);
         } else if (!(pl.dbg & 4)) {
-            const int t_first = next_diag ? 4 : 0, w3 = wave - 1;
-            for (int base = t_first + w3; base < ntiles; base += 3 * TT) {
+            const int t_first = next_diag ? 4 : 0, w3 = wave < 4 ? wave - 1 : wave - 2;
+            for (int base = t_first + w3; base < ntiles && wave != 4; base += NT * TT) {
                 v4d old[TT];
 #pragma unroll
                 for (int i = 0; i < TT; ++i) {
-                    const int T = base + 3 * i;
+                    const int T = base + NT * i;
                     if (T < ntiles) {
                         const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
                         const int bi = Rows[s.Pi[pr]], bjb = Rows[s.Pj[pr]];
@@ -321,7 +327,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 }
 #pragma unroll
                 for (int i = 0; i < TT; ++i) {
-                    const int T = base + 3 * i;
+                    const int T = base + NT * i;
                     if (T < ntiles) {
                         const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
                         const int qi = s.Pi[pr], qj = s.Pj[pr];
@@ -352,6 +358,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                     else rhs[bi * SNB + (t & 31)] = rhs_old[u] - v;
                 }
             }
+            if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 3] = (long long)__builtin_amdgcn_s_memtime();
         }
         __syncthreads();                    // full: the next panel stages from what this one wrote to global
         STAMP(6);
