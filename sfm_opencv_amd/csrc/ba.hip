@@ -345,9 +345,9 @@ static int enqueue_solve(sfmhip_ba* h)
                 std::vector<long long> hs(16 * (size_t)nb);
                 (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 for (int k = 0; k < nb; ++k) {
-                    fprintf(stderr, "[stamps] panel %3d: stage %6lld | solve %6lld | next pivot %6lld | factor (wave 0) %6lld | trailing + rhs (wave 1) %6lld | join %6lld   cycles\n", k,
+                    fprintf(stderr, "[stamps] panel %3d: stage %6lld | solve %6lld | next pivot %6lld | factor (wave 0) %6lld | trailing tiles %6lld + rhs %6lld (wave 1) | join %6lld   cycles\n", k,
                             hs[16 * k + 1] - hs[16 * k + 0], hs[16 * k + 4] - hs[16 * k + 1], hs[16 * k + 5] - hs[16 * k + 4],
-                            hs[16 * k + 2] - hs[16 * k + 5], hs[16 * k + 3] - hs[16 * k + 5], hs[16 * k + 6] - hs[16 * k + 2]);
+                            hs[16 * k + 2] - hs[16 * k + 5], hs[16 * k + 7] - hs[16 * k + 5], hs[16 * k + 3] - hs[16 * k + 7], hs[16 * k + 6] - hs[16 * k + 2]);
                     if (k + 1 < nb) fprintf(stderr, "[stamps]            to the next panel's start: %lld\n", hs[16 * (k + 1)] - hs[16 * k + 6]);
                 }
             }

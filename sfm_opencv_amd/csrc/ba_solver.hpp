@@ -66,7 +66,10 @@ struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
     int Rows2[2][SRMAX];                // block rows of the current / next panel (double-buffered by panel parity)
-    int Pi[SRMAX * (SRMAX + 1) / 2], Pj[SRMAX * (SRMAX + 1) / 2];     // block-pair list of the trailing update
+    // trailing-update tiles of the current panel: { row of the A operand in B, row of the B operand, target address of the
+    // tile's (0,0) element (lo, hi) }, and the target's leading dimension
+    int4 Tile[2][SRMAX * (SRMAX + 1) / 2 * 4];       // double-buffered by panel parity: wave 4 fills the next panel's table
+    int TileLd[2][SRMAX * (SRMAX + 1) / 2 * 4];      // while the other waves walk the current one
 };
 
 // One wave: in-place Cholesky of the 32x32 block in s.D (lower) AND the inverse of the factor, in the same 32 pivot steps:
@@ -194,17 +197,35 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     const int r0 = tid >> 5, c = tid & 31;
     const int ntop = (pl.nb - pl.top_blk) * SNB;
     bool ok = true;
-    constexpr int TT = 8;                // trailing tiles per wave whose old values are requested together
     constexpr int NT = SWAVES - 2;       // waves that share the trailing update: all but wave 0 (pivot chain) and wave 4, which
                                          // shares wave 0's SIMD (the chain runs 8 % slower with a busy neighbour)
     const int li = lane & 15, lk = lane >> 4;
 #define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     if (k0 >= k1) return true;
+    // tile table of panel kk (rows in s.Rows2[kk & 1]): tile T = 4 * pair + 2 * tr + tc, pairs (qi >= qj) in row-major order
+    // of the lower triangle; entries first, first + step, ...
+    auto fill_tiles = [&](int kk, int first, int step) {
+        const int Rk = pl.prow_start[kk + 1] - pl.prow_start[kk], nt = Rk * (Rk + 1) / 2 * 4;
+        const int* Rw = s.Rows2[kk & 1];
+        for (int T = first; T < nt; T += step) {
+            const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+            int qi = 0, qj = pr; while (qj > qi) { qj -= qi + 1; ++qi; }
+            const int bi = Rw[qi], bjb = Rw[qj];
+            double* dst; int dld;
+            if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+            else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
+            dst += (size_t)(16 * tr) * dld + 16 * tc;
+            const unsigned long long u = (unsigned long long)dst;
+            s.Tile[kk & 1][T] = make_int4(qi * SNB + 16 * tr, qj * SNB + 16 * tc, (int)(unsigned)u, (int)(unsigned)(u >> 32));
+            s.TileLd[kk & 1][T] = dld;
+        }
+    };
     // prologue: first pivot block, and the first panel's block-row list
     { const int q0 = pl.prow_start[k0], Rq = pl.prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows2[k0 & 1][tid] = pl.prow[q0 + tid]; }
     for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k0 * SNB + r) * ld + k0 * SNB + c];
     __syncthreads();
     if (wave == 0 && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
+    else if (wave > 0) fill_tiles(k0, tid - 64, STHREADS - 64);
     __syncthreads();
     for (int k = k0; k < k1; ++k) {
         const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
@@ -214,7 +235,6 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         STAMP(0);
         int* Rows = s.Rows2[k & 1];       // written one panel ago (before the full barrier): no dependent index load in front of the staging
         if (has_next) { const int q0 = pl.prow_start[k + 1], Rq = pl.prow_start[k + 2] - q0; if (tid < Rq) s.Rows2[(k + 1) & 1][tid] = pl.prow[q0 + tid]; }
-        if (tid < npairs) { int qi = 0, rem = tid; while (rem > qi) { rem -= qi + 1; ++qi; } s.Pi[tid] = qi; s.Pj[tid] = rem; }
         // requests whose latency hides behind the staging and the panel solve: this wave's tile of the next pivot block
         // and the right-hand-side entries waves 1..3 update in step 4
         v4d old0 = { 0.0, 0.0, 0.0, 0.0 };
@@ -308,51 +328,62 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             if (has_next && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
             STAMP(2);
         } else if (!(pl.dbg & 4)) {
+            // this wave's tiles T = t_first + w3 + NT i, two at a time so that their MFMA chains interleave.  An index past
+            // the last tile is clamped (a dummy tile: computed, not stored), so the body has no divergent control flow.
             const int t_first = next_diag ? 4 : 0, w3 = wave < 4 ? wave - 1 : wave - 2;
-            for (int base = t_first + w3; base < ntiles && wave != 4; base += NT * TT) {
-                v4d old[TT];
+            const int n_mine = (wave == 4) ? 0 : (ntiles - t_first - w3 + NT - 1) / NT;
+            if (wave == 4 && has_next) fill_tiles(k + 1, lane, 64);
+            struct TileRef { const double* a; const double* b; double* dst; int dld; };
+            auto tile_ref = [&](int i) -> TileRef {
+                int T = t_first + w3 + NT * i;
+                if (T > ntiles - 1) T = ntiles - 1;
+                const int4 d = s.Tile[k & 1][T];
+                const int dld = s.TileLd[k & 1][T];
+                double* dst = (double*)(((unsigned long long)(unsigned)d.w << 32) | (unsigned long long)(unsigned)d.z) + (size_t)lk * dld + li;
+                return TileRef{ &s.B[d.x + li][lk], &s.B[d.y + li][lk], dst, dld };
+            };
+            // A_ij -= X_i X_j' goes out as a hardware fp64 atomic add of the negated product (no return value): the target
+            // is touched by exactly one lane per panel and the panels are separated by barriers, so the result is the same
+            // single rounding as old - acc in a fixed order, without the ~3k-cycle read of the old tile in front of it.
+            auto do_pair = [&](const TileRef& r0, const TileRef& r1, bool second) {
+                double a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
-                for (int i = 0; i < TT; ++i) {
-                    const int T = base + NT * i;
-                    if (T < ntiles) {
-                        const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
-                        const int bi = Rows[s.Pi[pr]], bjb = Rows[s.Pj[pr]];
-                        const double* src; int dld;
-                        if (HAS_TOP && bjb >= pl.top_blk) { src = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
-                        else { src = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
-                        src += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
+                for (int kk = 0; kk < 8; ++kk) { a0[kk] = r0.a[4 * kk]; b0[kk] = r0.b[4 * kk]; a1[kk] = r1.a[4 * kk]; b1[kk] = r1.b[4 * kk]; }
+                v4d c0 = { 0.0, 0.0, 0.0, 0.0 }, c1 = { 0.0, 0.0, 0.0, 0.0 };
+                if (!(pl.dbg & 32)) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) old[i][g] = src[(size_t)(4 * g) * dld];
-                    }
+                for (int kk = 0; kk < 8; ++kk) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], c1, 0, 0, 0);
                 }
+                } else { c0[0] = a0[0] + b0[1] + a0[2] + b0[3] + a0[4] + b0[5] + a0[6] + b0[7]; c1[0] = a1[0] + b1[1] + a1[2] + b1[3] + a1[4] + b1[5] + a1[6] + b1[7]; }
+                if (pl.dbg & 16) { if (c0[0] + c1[0] + c0[1] + c1[1] + c0[2] + c1[2] + c0[3] + c1[3] == 1.2345) r0.dst[0] = 0.0; return; }
 #pragma unroll
-                for (int i = 0; i < TT; ++i) {
-                    const int T = base + NT * i;
-                    if (T < ntiles) {
-                        const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
-                        const int qi = s.Pi[pr], qj = s.Pj[pr];
-                        v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+                for (int g = 0; g < 4; ++g) unsafeAtomicAdd(r0.dst + (size_t)(4 * g) * r0.dld, -c0[g]);
+                if (second) {
 #pragma unroll
-                        for (int kk = 0; kk < 8; ++kk)
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s.B[qi * SNB + 16 * tr + li][4 * kk + lk],
-                                                                       s.B[qj * SNB + 16 * tc + li][4 * kk + lk], acc, 0, 0, 0);
-                        const int bi = Rows[qi], bjb = Rows[qj];
-                        double* dst; int dld;
-                        if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
-                        else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
-                        dst += (size_t)(16 * tr + lk) * dld + 16 * tc + li;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) dst[(size_t)(4 * g) * dld] = old[i][g] - acc[g];
-                    }
+                    for (int g = 0; g < 4; ++g) unsafeAtomicAdd(r1.dst + (size_t)(4 * g) * r1.dld, -c1[g]);
+                }
+            };
+            if (n_mine > 0) {
+                TileRef r0 = tile_ref(0), r1 = tile_ref(1);
+                for (int i = 0; i < n_mine; i += 2) {
+                    const TileRef n0 = tile_ref(i + 2), n1 = tile_ref(i + 3);      // next pair's lookups under this pair's MFMAs
+                    do_pair(r0, r1, i + 1 < n_mine);
+                    r0 = n0; r1 = n1;
                 }
             }
+            if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 7] = (long long)__builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = tid - 64 + u * (STHREADS - 64);
                 if (t < R * SNB) {
-                    double v = 0.0;
-#pragma unroll 8
-                    for (int m = 0; m < SNB; ++m) v += s.B[t][m] * s.B[R * SNB][m];
+                    double v4[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int m = 0; m < SNB; m += 4)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = fma(s.B[t][m + j], s.B[R * SNB][m + j], v4[j]);
+                    const double v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
                     const int bi = Rows[t >> 5];
                     if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] = rhs_old[u] - v;
                     else rhs[bi * SNB + (t & 31)] = rhs_old[u] - v;
