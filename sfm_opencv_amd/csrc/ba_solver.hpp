@@ -66,10 +66,11 @@ struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
     int Rows2[2][SRMAX];                // block rows of the current / next panel (double-buffered by panel parity)
-    // trailing-update tiles of the current panel: { row of the A operand in B, row of the B operand, target address of the
-    // tile's (0,0) element (lo, hi) }, and the target's leading dimension
-    int4 Tile[2][SRMAX * (SRMAX + 1) / 2 * 4];       // double-buffered by panel parity: wave 4 fills the next panel's table
-    int TileLd[2][SRMAX * (SRMAX + 1) / 2 * 4];      // while the other waves walk the current one
+    // trailing-update block pairs of the current panel: { first row of the A operand in B, first row of the B operand,
+    // address of the 32x32 target block (lo, hi) } and the target's leading dimension; double-buffered by panel parity
+    // (the idle wave fills the next panel's table while the others walk the current one)
+    int4 Pair[2][SRMAX * (SRMAX + 1) / 2];
+    int PairLd[2][SRMAX * (SRMAX + 1) / 2];
 };
 
 // One wave: in-place Cholesky of the 32x32 block in s.D (lower) AND the inverse of the factor, in the same 32 pivot steps:
@@ -202,22 +203,19 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     const int li = lane & 15, lk = lane >> 4;
 #define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     if (k0 >= k1) return true;
-    // tile table of panel kk (rows in s.Rows2[kk & 1]): tile T = 4 * pair + 2 * tr + tc, pairs (qi >= qj) in row-major order
-    // of the lower triangle; entries first, first + step, ...
-    auto fill_tiles = [&](int kk, int first, int step) {
-        const int Rk = pl.prow_start[kk + 1] - pl.prow_start[kk], nt = Rk * (Rk + 1) / 2 * 4;
+    // block-pair table of panel kk (rows in s.Rows2[kk & 1]): pairs (qi >= qj) in row-major order of the lower triangle
+    auto fill_pairs = [&](int kk, int first, int step) {
+        const int Rk = pl.prow_start[kk + 1] - pl.prow_start[kk], np = Rk * (Rk + 1) / 2;
         const int* Rw = s.Rows2[kk & 1];
-        for (int T = first; T < nt; T += step) {
-            const int pr = T >> 2, tr = (T >> 1) & 1, tc = T & 1;
+        for (int pr = first; pr < np; pr += step) {
             int qi = 0, qj = pr; while (qj > qi) { qj -= qi + 1; ++qi; }
             const int bi = Rw[qi], bjb = Rw[qj];
             double* dst; int dld;
             if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
             else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
-            dst += (size_t)(16 * tr) * dld + 16 * tc;
             const unsigned long long u = (unsigned long long)dst;
-            s.Tile[kk & 1][T] = make_int4(qi * SNB + 16 * tr, qj * SNB + 16 * tc, (int)(unsigned)u, (int)(unsigned)(u >> 32));
-            s.TileLd[kk & 1][T] = dld;
+            s.Pair[kk & 1][pr] = make_int4(qi * SNB, qj * SNB, (int)(unsigned)u, (int)(unsigned)(u >> 32));
+            s.PairLd[kk & 1][pr] = dld;
         }
     };
     // prologue: first pivot block, and the first panel's block-row list
@@ -225,11 +223,11 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k0 * SNB + r) * ld + k0 * SNB + c];
     __syncthreads();
     if (wave == 0 && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
-    else if (wave > 0) fill_tiles(k0, tid - 64, STHREADS - 64);
+    else if (wave > 0) fill_pairs(k0, tid - 64, STHREADS - 64);
     __syncthreads();
     for (int k = k0; k < k1; ++k) {
         const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
-        const int npairs = R * (R + 1) / 2, ntiles = npairs * 4;
+        const int npairs = R * (R + 1) / 2;
         const bool has_next = k + 1 < k1;
         const bool next_diag = has_next && R > 0 && pl.prow[p0] == k + 1;         // this panel updates the next pivot block (uniform scalar load)
         STAMP(0);
@@ -243,11 +241,12 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g) old0[g] = src[(size_t)(4 * g) * ld];
         }
-        double rhs_old[2] = { 0.0, 0.0 };
+        double rhs_old[SRMAX / 2];           // wave 4 owns the right-hand-side update: rows lane, lane + 64, ...
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = tid - 64 + u * (STHREADS - 64);
-            if (wave > 0 && t < R * SNB) {
+        for (int u = 0; u < SRMAX / 2; ++u) {
+            const int t = lane + 64 * u;
+            rhs_old[u] = 0.0;
+            if (wave == 4 && t < R * SNB) {
                 const int bi = Rows[t >> 5];
                 rhs_old[u] = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (t & 31)] : rhs[bi * SNB + (t & 31)];
             }
@@ -328,56 +327,48 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             if (has_next && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
             STAMP(2);
         } else if (!(pl.dbg & 4)) {
-            // this wave's tiles T = t_first + w3 + NT i, two at a time so that their MFMA chains interleave.  An index past
-            // the last tile is clamped (a dummy tile: computed, not stored), so the body has no divergent control flow.
-            const int t_first = next_diag ? 4 : 0, w3 = wave < 4 ? wave - 1 : wave - 2;
-            const int n_mine = (wave == 4) ? 0 : (ntiles - t_first - w3 + NT - 1) / NT;
-            if (wave == 4 && has_next) fill_tiles(k + 1, lane, 64);
-            struct TileRef { const double* a; const double* b; double* dst; int dld; };
-            auto tile_ref = [&](int i) -> TileRef {
-                int T = t_first + w3 + NT * i;
-                if (T > ntiles - 1) T = ntiles - 1;
-                const int4 d = s.Tile[k & 1][T];
-                const int dld = s.TileLd[k & 1][T];
-                double* dst = (double*)(((unsigned long long)(unsigned)d.w << 32) | (unsigned long long)(unsigned)d.z) + (size_t)lk * dld + li;
-                return TileRef{ &s.B[d.x + li][lk], &s.B[d.y + li][lk], dst, dld };
-            };
-            // A_ij -= X_i X_j' goes out as a hardware fp64 atomic add of the negated product (no return value): the target
+            // this wave's block pairs P = p_first + w3 + NT i: a whole 32x32 target per step (2 x 2 tiles of 16 x 16 from two
+            // A-operand and two B-operand row tiles: 32 LDS reads for 32 MFMAs; tile by tile it was 32 reads for 16 and
+            // the six waves saturated the LDS pipe: 1.7k of 2.9k cycles per tile pair).
+            // A_ij -= X_i X_j' goes out as a hardware fp64 atomic add of the negated product (no return value): each element
             // is touched by exactly one lane per panel and the panels are separated by barriers, so the result is the same
-            // single rounding as old - acc in a fixed order, without the ~3k-cycle read of the old tile in front of it.
-            auto do_pair = [&](const TileRef& r0, const TileRef& r1, bool second) {
-                double a0[8], b0[8], a1[8], b1[8];
+            // single rounding as old - acc in a fixed order, without a read of the old block in front of it.
+            const int p_first = next_diag ? 1 : 0, w3 = wave < 4 ? wave - 1 : wave - 2;
+            const int n_mine = (wave == 4) ? 0 : (npairs - p_first - w3 + NT - 1) / NT;
+            if (wave == 4 && has_next) fill_pairs(k + 1, lane, 64);
+            for (int i = 0; i < n_mine; ++i) {
+                const int P = p_first + w3 + NT * i;
+                const int4 d = s.Pair[k & 1][P];
+                const int dld = s.PairLd[k & 1][P];
+                double* dst = (double*)(((unsigned long long)(unsigned)d.w << 32) | (unsigned long long)(unsigned)d.z) + (size_t)lk * dld + li;
+                const double* pa = &s.B[d.x + li][lk];
+                const double* pb = &s.B[d.y + li][lk];
+                double a0[8], a1[8], b0[8], b1[8];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) { a0[kk] = r0.a[4 * kk]; b0[kk] = r0.b[4 * kk]; a1[kk] = r1.a[4 * kk]; b1[kk] = r1.b[4 * kk]; }
-                v4d c0 = { 0.0, 0.0, 0.0, 0.0 }, c1 = { 0.0, 0.0, 0.0, 0.0 };
+                for (int kk = 0; kk < 8; ++kk) { a0[kk] = pa[4 * kk]; b0[kk] = pb[4 * kk]; a1[kk] = pa[16 * SLD + 4 * kk]; b1[kk] = pb[16 * SLD + 4 * kk]; }
+                v4d c00 = { 0.0, 0.0, 0.0, 0.0 }, c01 = c00, c10 = c00, c11 = c00;
                 if (!(pl.dbg & 32)) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], c1, 0, 0, 0);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], c00, 0, 0, 0);
+                        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b1[kk], c01, 0, 0, 0);
+                        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b0[kk], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], c11, 0, 0, 0);
+                    }
                 }
-                } else { c0[0] = a0[0] + b0[1] + a0[2] + b0[3] + a0[4] + b0[5] + a0[6] + b0[7]; c1[0] = a1[0] + b1[1] + a1[2] + b1[3] + a1[4] + b1[5] + a1[6] + b1[7]; }
-                if (pl.dbg & 16) { if (c0[0] + c1[0] + c0[1] + c1[1] + c0[2] + c1[2] + c0[3] + c1[3] == 1.2345) r0.dst[0] = 0.0; return; }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) unsafeAtomicAdd(r0.dst + (size_t)(4 * g) * r0.dld, -c0[g]);
-                if (second) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) unsafeAtomicAdd(r1.dst + (size_t)(4 * g) * r1.dld, -c1[g]);
-                }
-            };
-            if (n_mine > 0) {
-                TileRef r0 = tile_ref(0), r1 = tile_ref(1);
-                for (int i = 0; i < n_mine; i += 2) {
-                    const TileRef n0 = tile_ref(i + 2), n1 = tile_ref(i + 3);      // next pair's lookups under this pair's MFMAs
-                    do_pair(r0, r1, i + 1 < n_mine);
-                    r0 = n0; r1 = n1;
+                for (int g = 0; g < 4; ++g) {
+                    unsafeAtomicAdd(dst + (size_t)(4 * g) * dld, -c00[g]);
+                    unsafeAtomicAdd(dst + (size_t)(4 * g) * dld + 16, -c01[g]);
+                    unsafeAtomicAdd(dst + (size_t)(16 + 4 * g) * dld, -c10[g]);
+                    unsafeAtomicAdd(dst + (size_t)(16 + 4 * g) * dld + 16, -c11[g]);
                 }
             }
             if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 7] = (long long)__builtin_amdgcn_s_memtime();
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = tid - 64 + u * (STHREADS - 64);
-                if (t < R * SNB) {
+            for (int u = 0; u < SRMAX / 2; ++u) {
+                const int t = lane + 64 * u;
+                if (wave == 4 && t < R * SNB) {
                     double v4[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
                     for (int m = 0; m < SNB; m += 4)
