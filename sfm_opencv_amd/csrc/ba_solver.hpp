@@ -100,6 +100,15 @@ __device__ __forceinline__ double rsqrt_refined(double d)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// fire-and-forget fp64 add into global memory.  The address-space cast matters: a pointer rebuilt from a table is
+// generic, the compiler would emit flat_atomic_add_f64, and flat operations also count in lgkmcnt -- every LDS wait
+// after them would wait for the atomics' round trip to L2 as well.
+typedef __attribute__((address_space(1))) double global_f64;
+__device__ __forceinline__ void global_add_f64(double* p, double v)
+{
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((global_f64*)p, v);
+}
+
 __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 {
     const bool lower = lane < SNB;
@@ -358,10 +367,10 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    unsafeAtomicAdd(dst + (size_t)(4 * g) * dld, -c00[g]);
-                    unsafeAtomicAdd(dst + (size_t)(4 * g) * dld + 16, -c01[g]);
-                    unsafeAtomicAdd(dst + (size_t)(16 + 4 * g) * dld, -c10[g]);
-                    unsafeAtomicAdd(dst + (size_t)(16 + 4 * g) * dld + 16, -c11[g]);
+                    global_add_f64(dst + (size_t)(4 * g) * dld, -c00[g]);
+                    global_add_f64(dst + (size_t)(4 * g) * dld + 16, -c01[g]);
+                    global_add_f64(dst + (size_t)(16 + 4 * g) * dld, -c10[g]);
+                    global_add_f64(dst + (size_t)(16 + 4 * g) * dld + 16, -c11[g]);
                 }
             }
             if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 7] = (long long)__builtin_amdgcn_s_memtime();
