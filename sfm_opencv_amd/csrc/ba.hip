@@ -333,7 +333,7 @@ static int enqueue_solve(sfmhip_ba* h)
     const int nb = h->nbk, ld = h->npad;
     if (h->use_sparse) {
         double* rhs_rw = h->d_msg + (size_t)h->npad * h->npad;
-        SolverPlan pl; pl.prow_start = h->d_prow_start; pl.prow = h->d_prow; pl.nb = nb; pl.top_blk = h->top_blk;
+        SolverPlan pl; pl.prow_start = h->d_prow_start; pl.prow = h->d_prow; pl.nb = nb; pl.top_blk = h->top_blk; pl.linv = h->d_Linv;
         { const char* e = getenv("SFMHIP_EXP_SOLVER"); pl.dbg = e ? atoi(e) : 0; }
         static long long* d_stamps = nullptr; static int stamp_calls = 0;
         pl.stamps = nullptr;

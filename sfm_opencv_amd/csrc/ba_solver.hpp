@@ -188,6 +188,7 @@ struct SolverPlan {
     int nb, top_blk;             // top_blk == nb: no shared top
     int dbg;                     // timing experiments only (SFMHIP_EXP_SOLVER): skip phases, results are garbage
     long long* stamps;           // diagnostic (SFMHIP_SOLVER_STAMPS): s_memtime at the phase boundaries of each panel, 8 per panel
+    double* linv;                // (L_kk^-1)' of every pivot block, 32x32 each, written by the forward sweep for the backward one
 };
 
 template <bool HAS_TOP>
@@ -277,7 +278,10 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 }
             }
             if (wave == 3 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
-            for (int r = r0; r < SNB; r += SROWS) A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
+            for (int r = r0; r < SNB; r += SROWS) {
+                A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
+                pl.linv[(size_t)k * SNB * SNB + r * SNB + c] = s.W[SNB + r][c];
+            }
         }
         lds_barrier();
         STAMP(1);
@@ -398,40 +402,58 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     return ok;
 }
 
-// L' y = z for panels k_hi-1 .. k_lo (descending); sy holds z for those panels and y for every later block they use
+// L' y = z for panels k_hi-1 .. k_lo (descending); sy holds z for those panels and y for every later block they use.
+//     t = z_k - sum_i L_ik' y_i,   y_k = (L_kk^-1)' t
+// with the inverse the forward sweep left in pl.linv (one 32x32 product instead of a 32-step substitution chain), and
+// the next panel's blocks requested one panel ahead (their addresses do not depend on y): a panel costs two barriers
+// and two short LDS passes instead of an L2 round trip plus the chain.
 __device__ __forceinline__ void backward_panels(SolverLds& s, const double* __restrict__ A, int ld, int k_lo, int k_hi,
                                                 const SolverPlan pl, double* sy)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = tid >> 5, c = tid & 31;
-    for (int k = k_hi - 1; k >= k_lo; --k) {
-        const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
-        for (int r = r0; r < SNB; r += SROWS) {
-            s.D[r][c] = A[(size_t)(k * SNB + r) * ld + k * SNB + c];
-            double part = 0.0;
-#pragma unroll 4
-            for (int q = 0; q < R; ++q) {
+    const int r0 = tid >> 5, c = tid & 31;          // this thread's elements: rows r0 and r0 + 16 of column c
+    if (k_hi <= k_lo) return;
+    struct PanelRegs { double lb[SRMAX][2]; double wt[2]; int rows[SRMAX]; int R; };
+    auto load_panel = [&](PanelRegs& P, int k) {
+        const int p0 = pl.prow_start[k];
+        P.R = pl.prow_start[k + 1] - p0;
+#pragma unroll
+        for (int q = 0; q < SRMAX; ++q) {
+            P.rows[q] = 0; P.lb[q][0] = 0.0; P.lb[q][1] = 0.0;
+            if (q < P.R) {
                 const int i = pl.prow[p0 + q];
-                part += A[(size_t)(i * SNB + r) * ld + k * SNB + c] * sy[i * SNB + r];
+                P.rows[q] = i;
+                P.lb[q][0] = A[(size_t)(i * SNB + r0) * ld + k * SNB + c];
+                P.lb[q][1] = A[(size_t)(i * SNB + r0 + 16) * ld + k * SNB + c];
             }
-            s.Red[r][c] = part;
         }
+        P.wt[0] = pl.linv[(size_t)k * SNB * SNB + r0 * SNB + c];
+        P.wt[1] = pl.linv[(size_t)k * SNB * SNB + (r0 + 16) * SNB + c];
+    };
+    PanelRegs cur, nxt;
+    load_panel(cur, k_hi - 1);
+    nxt = cur;
+    for (int k = k_hi - 1; k >= k_lo; --k) {
+        if (k > k_lo) load_panel(nxt, k - 1);
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < SRMAX; ++q)
+            if (q < cur.R) part += cur.lb[q][0] * sy[cur.rows[q] * SNB + r0] + cur.lb[q][1] * sy[cur.rows[q] * SNB + r0 + 16];
+        s.Red[r0][c] = part;
+        s.D[r0][c] = cur.wt[0]; s.D[r0 + 16][c] = cur.wt[1];
         __syncthreads();
         if (wave == 0) {
             const int l = lane & 31;
             double t = sy[k * SNB + l];
 #pragma unroll
-            for (int rr = 0; rr < SNB; ++rr) t -= s.Red[rr][l];
-            const double inv = 1.0 / s.D[l][l];
+            for (int rr = 0; rr < SROWS; ++rr) t -= s.Red[rr][l];
+            double y4[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int cc = SNB - 1; cc >= 0; --cc) {
-                const double yc = readlane_f64(t * inv, cc);
-                if (l == cc) t = yc;
-                else if (l < cc) t -= s.D[cc][l] * yc;
-            }
-            if (lane < 32) sy[k * SNB + l] = t;
+            for (int m = 0; m < SNB; ++m) y4[m & 3] = fma(s.D[l][m], readlane_f64(t, m), y4[m & 3]);
+            if (lane < 32) sy[k * SNB + l] = (y4[0] + y4[1]) + (y4[2] + y4[3]);
         }
         __syncthreads();
+        cur = nxt;
     }
 }
 
