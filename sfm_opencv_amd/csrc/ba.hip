@@ -203,6 +203,8 @@ struct sfmhip_ba {
     int iter_parity = 0, pending_build = -1, pending_iter = -1;       // timings not yet read (read off the decision path)
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
+    bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
+    unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
@@ -272,8 +274,11 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
         SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
     }
     h->cleared = false;
-    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, at_candidate ? h->d_extc : h->d_ext, h->nc,
-                       at_candidate ? h->d_campre_c : h->d_campre);
+    // rotation blocks: the candidate's are computed with the step (ba_camstep_kernel) and swapped in when it is accepted
+    if (!at_candidate && !h->campre_valid) {
+        hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
+        h->campre_valid = true;
+    }
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
     // The camera kernel and the Schur pair kernel both depend only on the point kernel and both leave issue slots idle, so
     // they run side by side: the pair kernel on the auxiliary stream, its partials folded into S (ba_schur_reduce_kernel,
@@ -386,7 +391,6 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     hipStream_t st = ctx->stream;
     BADev P = make_dev(h, radius);
     hipLaunchKernelGGL(ba_camstep_kernel, dim3(1), dim3(256), 0, st, P, h->d_cam2);
-    hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_extc, h->nc, h->d_campre_c);
     hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P);
     hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4);
     SFM_HIP_TRY(ctx, hipGetLastError());
@@ -617,15 +621,13 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
         rc = enqueue_back(h, h->radius); if (rc) return rc;
         SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal, d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 2, h->d_back4, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 6, h->d_cam2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->h_scal + 8, h->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+        // one wave gathers the nine scalars into pinned host memory and bumps a sequence number the host polls; it also
+        // re-arms the error flag.  The next build's zero-fill does not depend on the decision: it runs while the host decides.
+        const unsigned long long seq = ++h->pub_seq;
+        hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
-        // the next build's zero-fills do not depend on the decision: run them while the host waits for the scalars
         if (!h->ar_fn) {
             SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
-            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
             h->cleared = true;
         }
         // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
@@ -635,10 +637,20 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
         read_pending_timing(h);                     // the PREVIOUS iteration's events, while the GPU works on this one
         h->pending_build = par; h->pending_iter = h->iter_parity;
-        SFM_HIP_TRY(ctx, hipEventSynchronize(h->ev_scal));
+        {   // spin on the sequence number; fall back to the event if the stream stops without publishing (a failed launch)
+            volatile unsigned long long* flag = (volatile unsigned long long*)(h->h_scal + 15);
+            unsigned spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0x3fff) == 0 && hipEventQuery(h->ev_scal) != hipErrorNotReady) {
+                    SFM_HIP_TRY(ctx, hipEventSynchronize(h->ev_scal));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->last_error = "bundle adjustment: the step scalars were not published"; return SFMHIP_E_HIP; }
+                    break;
+                }
+            }
+        }
         const double cost = h->h_scal[0], gmax = h->h_scal[1], mcc = h->h_scal[2], cand_raw = h->h_scal[3];
         const double dn = h->h_scal[4] + h->h_scal[6], xn = h->h_scal[5] + h->h_scal[7];
-        int err = 0; memcpy(&err, h->h_scal + 8, sizeof(int));
+        const int err = (int)h->h_scal[8];
         h->x_cost = cost; h->gmax = gmax;
         if (h->initial_cost < 0.0) h->initial_cost = cost;
         if (!std::isfinite(cost)) { h->termination = SFMHIP_BA_FAILURE; ctx->last_error = "non-finite cost"; break; }
@@ -838,6 +850,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dalloc(h, &h->d_msg, std::max(h->msg_count, (size_t)h->ncf * h->ncf)));
 #undef TRY_RC
     if (hipHostMalloc((void**)&h->h_scal, 16 * sizeof(double)) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipHostMalloc"; return SFMHIP_E_HIP; }
+    memset(h->h_scal, 0, 16 * sizeof(double));
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evb) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evi) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
@@ -853,7 +866,7 @@ int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, in
 {
     if (!h || world < 1 || world > 64 || rank < 0 || rank >= world) return SFMHIP_E_ARG;
     h->ar_fn = fn; h->ar_user = user; h->rank = rank; h->world = world;
-    h->started = false; h->built = false; h->cleared = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
     return SFMHIP_OK;
 }
 
@@ -864,7 +877,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_K, h->d_K0, 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ext, h->d_ext0, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (h->np) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts, h->d_pts0, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    h->started = false; h->built = false; h->cleared = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     return SFMHIP_OK;
 }
@@ -873,7 +886,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
-    h->started = false; h->built = false; h->cleared = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
     const int rc = ba_loop(h, h->o.max_num_iterations, false);
     fill_summary(h, summary, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;

@@ -103,12 +103,8 @@ __device__ __forceinline__ void rotate_with_derivs(const double* __restrict__ e,
 }
 
 // pre[36] per camera: R row-major (9), then dR/dw_m row-major (9 each, m = 0..2)
-__global__ void ba_campre_kernel(const double* __restrict__ ext, int nc, double* __restrict__ pre)
+__device__ __forceinline__ void campre_one(const double* __restrict__ e, double* __restrict__ o)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nc) return;
-    const double* e = ext + 6 * c;
-    double* o = pre + 36 * (size_t)c;
 #pragma unroll
     for (int col = 0; col < 3; ++col) {
         const double X[3] = { col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0 };
@@ -121,6 +117,12 @@ __global__ void ba_campre_kernel(const double* __restrict__ ext, int nc, double*
             for (int m = 0; m < 3; ++m) o[9 + 9 * m + 3 * k + col] = dpw[m][k];
         }
     }
+}
+
+__global__ void ba_campre_kernel(const double* __restrict__ ext, int nc, double* __restrict__ pre)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nc) campre_one(ext + 6 * c, pre + 36 * (size_t)c);
 }
 
 // 1/sqrt(d) and 1/d by the hardware seed + two Newton steps (~1 ulp): 7 / 5 dependent ops, where sqrt() and the IEEE
@@ -770,11 +772,29 @@ __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __rest
     }
     dn = wave_sum(dn); xn = wave_sum(xn);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = dn; red[threadIdx.x >> 6][1] = xn; }
-    __syncthreads();
+    __syncthreads();                        // also: the candidate extrinsics written above are visible to the whole block
     if (threadIdx.x == 0) {
         out2[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         out2[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
+    // the candidate cameras' rotation blocks (what ba_campre_kernel computes), in the same launch
+    for (int c = threadIdx.x; c < P.nc; c += 256) campre_one(P.extc + 6 * c, const_cast<double*>(P.campre_c) + 36 * (size_t)c);
+}
+
+// The scalars the host needs to accept or reject the step, gathered into pinned host memory by one wave, then a sequence
+// number with system-scope release: the host polls it.  (Four 8..32-byte copies cost ~5 us each on the stream.)
+// host_out: [cost, gmax, mcc, cand, dn_p, xn_p, dn_c, xn_c, err] + seq at [15]
+__global__ void ba_publish_kernel(const double* __restrict__ scal2, const double* __restrict__ back4, const double* __restrict__ cam2,
+                                  int* __restrict__ err, double* __restrict__ host_out, unsigned long long seq, int clear_err)
+{
+    const int l = threadIdx.x;
+    if (l < 2) host_out[l] = scal2[l];
+    else if (l < 6) host_out[l] = back4[l - 2];
+    else if (l < 8) host_out[l] = cam2[l - 6];
+    else if (l == 8) { host_out[8] = (double)*err; if (clear_err) *err = 0; }
+    __threadfence_system();
+    __syncthreads();
+    if (l == 0) __hip_atomic_store((unsigned long long*)(host_out + 15), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------
