@@ -193,7 +193,8 @@ def main():
         roof_ba = {"kernel": dom, "bound": "hbm", "achieved": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                    "traffic": None, "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
-                   "note": "largest kernel of one LM iteration; at C4 every BA kernel is latency-bound (0.7 ms for 106 MB), see DESIGN.md 7"}
+                   "note": f"largest kernel of one LM iteration; every BA kernel is latency-bound at this size ({phase[3]:.2f} ms of device time "
+                           f"for {b_it / 1e6:.0f} MB), see DESIGN.md 7"}
         # the kernel with the most GPU time of the whole bench step: the fused int8 kNN-2 kernel of the matching pass
         roof = roof_ba
         if n_pairs_l and knn_calls:
