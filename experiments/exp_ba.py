@@ -33,6 +33,7 @@ def run(ctx, sc, env, steps=8):
 
 if __name__ == "__main__":
     ctx = api.Context(0, use_torch_stream=True)
+    ctx.set_kernel_timing(True)       # sfmhip_ba_phase_ms needs the event instrumentation
     cfg = synth.CONFIGS["C4"]
     sc = synth.ba_scene(cfg["n_img"], cfg["n_pt"])
     variants = [json.loads(a) for a in sys.argv[1:]] or [{}]

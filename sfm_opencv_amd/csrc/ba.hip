@@ -203,6 +203,8 @@ struct sfmhip_ba {
     int iter_parity = 0, pending_build = -1, pending_iter = -1;       // timings not yet read (read off the decision path)
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
+    bool top_cleared = false;      // d_topbuf was zero-filled ahead of time (behind the publish kernel, while the host decides)
+    bool build_timed = false;      // the pending build recorded its events (timing can be switched between launches)
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
@@ -268,7 +270,9 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     hipStream_t st = ctx->stream;
     BADev P = make_dev(h, radius, at_candidate);       // the point blocks are damped with the radius while they are built
     hipEvent_t* tv = nullptr;
-    if (timed) { h->build_parity ^= 1; tv = h->evb[h->build_parity]; (void)hipEventRecord(tv[0], st); }
+    // phase / kernel events only while sfmhip_set_kernel_timing is on: thirteen event records cost ~27 us per iteration
+    if (timed) h->build_timed = ctx->timing;
+    if (timed && ctx->timing) { h->build_parity ^= 1; tv = h->evb[h->build_parity]; (void)hipEventRecord(tv[0], st); }
     if (!h->cleared) {
         SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
         SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_err, 0, sizeof(int), st));
@@ -361,10 +365,11 @@ static int enqueue_solve(sfmhip_ba* h)
             pl.top_blk = nb;
             hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, rhs_rw, h->d_y, h->d_err);
         } else {
-            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
-            (void)hipEventRecord(h->evi[h->iter_parity][3], st);
+            if (!h->top_cleared) SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
+            h->top_cleared = false;
+            if (ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][3], st);
             hipLaunchKernelGGL(chol_nd_forward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_topbuf, h->d_err);
-            (void)hipEventRecord(h->evi[h->iter_parity][4], st);
+            if (ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][4], st);
             hipLaunchKernelGGL(chol_nd_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->nseg, rhs_rw, h->d_topbuf, h->d_y, h->d_err);
             hipLaunchKernelGGL(chol_nd_backward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_y);
         }
@@ -616,11 +621,12 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         hipEvent_t* ti = h->evi[h->iter_parity];
         h->built = false;                           // damping and the in-place factorisation consume it
         rc = enqueue_damp(h, h->radius); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
+        const bool timing = ctx->timing && h->build_timed;
+        if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
         rc = enqueue_solve(h); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
+        if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
         rc = enqueue_back(h, h->radius); if (rc) return rc;
-        SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
+        if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
         // one wave gathers the nine scalars into pinned host memory and bumps a sequence number the host polls; it also
         // re-arms the error flag.  The next build's zero-fill does not depend on the decision: it runs while the host decides.
         const unsigned long long seq = ++h->pub_seq;
@@ -629,6 +635,7 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (!h->ar_fn) {
             SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
             h->cleared = true;
+            if (h->use_sparse && h->nseg > 1 && h->d_topbuf) { SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st)); h->top_cleared = true; }
         }
         // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
         // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
@@ -636,7 +643,7 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
         if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
         read_pending_timing(h);                     // the PREVIOUS iteration's events, while the GPU works on this one
-        h->pending_build = par; h->pending_iter = h->iter_parity;
+        if (timing) { h->pending_build = par; h->pending_iter = h->iter_parity; }
         {   // spin on the sequence number; fall back to the event if the stream stops without publishing (a failed launch)
             volatile unsigned long long* flag = (volatile unsigned long long*)(h->h_scal + 15);
             unsigned spins = 0;
@@ -866,7 +873,7 @@ int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, in
 {
     if (!h || world < 1 || world > 64 || rank < 0 || rank >= world) return SFMHIP_E_ARG;
     h->ar_fn = fn; h->ar_user = user; h->rank = rank; h->world = world;
-    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
     return SFMHIP_OK;
 }
 
@@ -877,7 +884,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_K, h->d_K0, 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ext, h->d_ext0, 6 * (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (h->np) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts, h->d_pts0, 3 * (size_t)h->np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
     return SFMHIP_OK;
 }
@@ -886,7 +893,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
-    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false;
+    h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
     const int rc = ba_loop(h, h->o.max_num_iterations, false);
     fill_summary(h, summary, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;
