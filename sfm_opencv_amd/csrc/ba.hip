@@ -291,12 +291,12 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         if (tv) (void)hipEventRecord(tv[3], h->aux);
-        hipLaunchKernelGGL(ba_schur_kernel, dim3(ceil_div(h->nchunk, 4)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(round_up(ceil_div(h->nchunk, 4), 8)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
         if (tv) (void)hipEventRecord(tv[4], h->aux);
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
     } else if (tv) { (void)hipEventRecord(tv[3], st); (void)hipEventRecord(tv[4], st); }
     if (tv) (void)hipEventRecord(tv[1], st);
-    hipLaunchKernelGGL(ba_camera_kernel, dim3(h->nc, h->cam_split, h->fixK ? 1 : 2), dim3(256), 0, st, P);     // z = 1: camera-intrinsic sums
+    hipLaunchKernelGGL(ba_camera_kernel, dim3(round_up(h->nc * h->cam_split * (h->fixK ? 1 : 2), 8)), dim3(256), 0, st, P);
     if (tv) (void)hipEventRecord(tv[2], st);
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
     if (h->nblk > 0) {
