@@ -165,11 +165,11 @@ def main():
         import oracle as orc
         cores = args.cpu_threads if args.cpu_threads > 0 else min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
         orc.set_num_threads(cores)
-        n_it_cpu = 3
+        n_it_cpu = 30 if args.config in ("C4", "C5") else 10      # ~10 s of CPU work at C4 (3 it/s on 16 threads)
         tc = time.perf_counter()
         orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], force_iterations=n_it_cpu)
         t_cpu_ba = time.perf_counter() - tc
-        cpu_pairs = 2
+        cpu_pairs = min(100, n_img - 1)                               # ~1-2 s: a secondary figure, the metric is BA iterations
         ch = chain if chain is not None and len(chain) > cpu_pairs else synth.sift_descriptor_chain(cpu_pairs + 1, n_desc)
         tc = time.perf_counter()
         for i in range(cpu_pairs):

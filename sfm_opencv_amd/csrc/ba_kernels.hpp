@@ -893,7 +893,7 @@ __device__ __forceinline__ double back_rec_value(const BADev& P, int c, int f)
     return 0.0;
 }
 
-__global__ __launch_bounds__(256) void ba_back_kernel(BADev P)
+__global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P)
 {
     __shared__ double red[4][4];
     __shared__ __attribute__((aligned(16))) double cam[BACK_NCL][BACK_REC];
