@@ -204,6 +204,7 @@ struct sfmhip_ba {
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
     bool top_cleared = false;      // d_topbuf was zero-filled ahead of time (behind the publish kernel, while the host decides)
+    bool solver_damps = false; double damp_radius = 0.0;    // the next enqueue_solve applies the LM damping inside its kernels
     bool build_timed = false;      // the pending build recorded its events (timing can be switched between launches)
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
@@ -343,6 +344,12 @@ static int enqueue_solve(sfmhip_ba* h)
     if (h->use_sparse) {
         double* rhs_rw = h->d_msg + (size_t)h->npad * h->npad;
         SolverPlan pl; pl.prow_start = h->d_prow_start; pl.prow = h->d_prow; pl.nb = nb; pl.top_blk = h->top_blk; pl.linv = h->d_Linv;
+        pl.damp_diagU = nullptr; pl.damp_mask = nullptr; pl.damp_radius = 1.0; pl.damp_min = pl.damp_max = 0.0;
+        if (h->solver_damps) {
+            BADev P = make_dev(h, h->damp_radius);
+            pl.damp_diagU = P.diagU; pl.damp_mask = P.posmask; pl.damp_radius = h->damp_radius; pl.damp_min = P.min_diag; pl.damp_max = P.max_diag;
+            h->solver_damps = false;
+        }
         { const char* e = getenv("SFMHIP_EXP_SOLVER"); pl.dbg = e ? atoi(e) : 0; }
         static long long* d_stamps = nullptr; static int stamp_calls = 0;
         pl.stamps = nullptr;
@@ -620,7 +627,8 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         h->iter_parity ^= 1;
         hipEvent_t* ti = h->evi[h->iter_parity];
         h->built = false;                           // damping and the in-place factorisation consume it
-        rc = enqueue_damp(h, h->radius); if (rc) return rc;
+        if (h->use_sparse) { h->solver_damps = true; h->damp_radius = h->radius; }     // damping rides in the solver kernels
+        else { rc = enqueue_damp(h, h->radius); if (rc) return rc; }
         const bool timing = ctx->timing && h->build_timed;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
         rc = enqueue_solve(h); if (rc) return rc;

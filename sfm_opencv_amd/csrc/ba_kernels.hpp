@@ -794,6 +794,22 @@ __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __rest
         out2[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         out2[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
+    // max |gradient| (what ba_damp_kernel reports when it runs; the sparse solvers damp S themselves): camera-side columns
+    // folded with the per-rank point maxima.  graw is not touched by the factorisation.
+    {
+        __shared__ double gred[4];
+        double g = 0.0;
+        for (int i = threadIdx.x; i < P.npad; i += 256)
+            if (P.posmask[i]) g = fmax(g, fabs(P.graw[i] / P.scale_c[i]));
+        g = wave_max(g);
+        if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = g;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = fmax(fmax(gred[0], gred[1]), fmax(gred[2], gred[3]));
+            for (int r = 0; r < P.world; ++r) m = fmax(m, P.scal[SCAL_GMAX_SLOTS + r]);
+            P.scal[1] = m;
+        }
+    }
     // the candidate cameras' rotation blocks (what ba_campre_kernel computes), in the same launch
     for (int c = threadIdx.x; c < P.nc; c += 256) campre_one(P.extc + 6 * c, const_cast<double*>(P.campre_c) + 36 * (size_t)c);
 }

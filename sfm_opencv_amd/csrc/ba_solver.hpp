@@ -189,6 +189,9 @@ struct SolverPlan {
     int dbg;                     // timing experiments only (SFMHIP_EXP_SOLVER): skip phases, results are garbage
     long long* stamps;           // diagnostic (SFMHIP_SOLVER_STAMPS): s_memtime at the phase boundaries of each panel, 8 per panel
     double* linv;                // (L_kk^-1)' of every pivot block, 32x32 each, written by the forward sweep for the backward one
+    // LM damping applied by the solver kernels themselves (one launch less per iteration): S_ii += clamp(diagU_i) / radius on
+    // real parameters, unit diagonal on padding slots; damp_diagU == nullptr: the caller has damped S already
+    const double* damp_diagU; const int* damp_mask; double damp_radius, damp_min, damp_max;
 };
 
 template <bool HAS_TOP>
@@ -457,12 +460,25 @@ __device__ __forceinline__ void backward_panels(SolverLds& s, const double* __re
     }
 }
 
+// rows [i0, i1) of S get their damping term (see SolverPlan); the caller synchronises before the rows are read
+__device__ __forceinline__ void damp_rows(double* __restrict__ A, int ld, const SolverPlan& pl, int i0, int i1)
+{
+    if (!pl.damp_diagU) return;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += STHREADS) {
+        double* d = A + (size_t)i * ld + i;
+        if (pl.damp_mask[i]) *d += fmin(fmax(pl.damp_diagU[i], pl.damp_min), pl.damp_max) / pl.damp_radius;
+        else *d = 1.0;
+    }
+}
+
 // single workgroup: whole factorisation + both substitutions (no shared top)
 __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restrict__ A, int ld, SolverPlan pl,
                                                                double* __restrict__ rhs, double* __restrict__ y, int* __restrict__ err)
 {
     __shared__ SolverLds s;
     const int tid = threadIdx.x;
+    damp_rows(A, ld, pl, 0, pl.nb * SNB);
+    __syncthreads();
     const bool ok = forward_panels<false>(s, A, ld, 0, pl.nb, pl, rhs, nullptr, nullptr);
     if (!ok && tid == 0) *err = 2;
     double* sy = &s.B[0][0];
@@ -482,6 +498,8 @@ __global__ __launch_bounds__(STHREADS) void chol_nd_forward_kernel(double* __res
     const int seg = blockIdx.x;
     const size_t ntop = (size_t)(pl.nb - pl.top_blk) * SNB;
     double* topA = topbuf + (size_t)seg * (ntop * ntop + ntop);
+    damp_rows(A, ld, pl, seg_blk[seg] * SNB, seg_blk[seg + 1] * SNB);
+    __syncthreads();
     const bool ok = forward_panels<true>(s, A, ld, seg_blk[seg], seg_blk[seg + 1], pl, rhs, topA, topA + ntop * ntop);
     if (!ok && threadIdx.x == 0) *err = 2;
 }
@@ -527,6 +545,8 @@ __global__ __launch_bounds__(STHREADS) void chol_nd_top_kernel(double* __restric
             rhs[t0 + i] = v;
         }
     }
+    __syncthreads();
+    damp_rows(A, ld, pl, t0, t0 + ntop);
     __syncthreads();
     SolverPlan top = pl; top.top_blk = pl.nb;
     const bool ok = forward_panels<false>(s, A, ld, pl.top_blk, pl.nb, top, rhs, nullptr, nullptr);
