@@ -204,6 +204,7 @@ struct sfmhip_ba {
     hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
     bool top_cleared = false;      // d_topbuf was zero-filled ahead of time (behind the publish kernel, while the host decides)
+    int n_diag_blk = 0;            // camera pairs (a, a): a point seen twice by one camera
     bool solver_damps = false; double damp_radius = 0.0;    // the next enqueue_solve applies the LM damping inside its kernels
     bool build_timed = false;      // the pending build recorded its events (timing can be switched between launches)
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
@@ -286,14 +287,15 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     }
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
     // The camera kernel and the Schur pair kernel both depend only on the point kernel and both leave issue slots idle, so
-    // they run side by side: the pair kernel on the auxiliary stream, its partials folded into S (ba_schur_reduce_kernel,
-    // the only writer) after the join.
+    // they run side by side: the pair kernel on the auxiliary stream, followed there by the fold of its partials into the
+    // off-diagonal blocks of S (ba_schur_reduce_kernel is their only writer); the rare (a, a) blocks after the join.
     if (h->nblk > 0) {
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         if (tv) (void)hipEventRecord(tv[3], h->aux);
         hipLaunchKernelGGL(ba_schur_kernel, dim3(round_up(ceil_div(h->nchunk, 4), 8)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
         if (tv) (void)hipEventRecord(tv[4], h->aux);
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, h->aux, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 0);
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
     } else if (tv) { (void)hipEventRecord(tv[3], st); (void)hipEventRecord(tv[4], st); }
     if (tv) (void)hipEventRecord(tv[1], st);
@@ -302,7 +304,8 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
     if (h->nblk > 0) {
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
-        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
+        if (h->n_diag_blk > 0)
+            hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
     }
     SFM_HIP_TRY(ctx, hipGetLastError());
     if (h->ar_fn) {
@@ -838,6 +841,8 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->nblk = (int)blk_cam.size() / 2;
     h->nchunk = (int)chunk_desc.size();
     h->host_blk_cam = blk_cam;
+    h->n_diag_blk = 0;
+    for (size_t b = 0; b + 1 < blk_cam.size(); b += 2) if (blk_cam[b] == blk_cam[b + 1]) ++h->n_diag_blk;
 
     int rc = SFMHIP_OK;
 #define TRY_RC(x) do { rc = (x); if (rc) { sfmhip_ba_destroy(h); return rc; } } while (0)

@@ -709,13 +709,17 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
     if (e < 36) part[36 * (size_t)chunk + e] = tot;
 }
 
+// diag_pass = 0: the off-diagonal blocks (the only writer of those: runs on the pair kernel's stream, beside K_cam and
+// K_finalize); diag_pass = 1: the a == b blocks, which add onto what K_finalize wrote (launched after the join, and only
+// when such blocks exist).
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
-                                                              int n_blk, const double* __restrict__ part)
+                                                              int n_blk, const double* __restrict__ part, int diag_pass)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int blk = t / 36, e = t % 36;
     if (blk >= n_blk) return;
     const int ca = blk_cam[2 * blk], cb = blk_cam[2 * blk + 1];
+    if ((ca == cb) != (diag_pass != 0)) return;
     const int oa = cam_off(P, ca), ob = cam_off(P, cb);
     const int i = e / 6, j = e % 6, eT = j * 6 + i;
     double sum = 0.0, sumT = 0.0;
