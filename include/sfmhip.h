@@ -56,7 +56,8 @@ int  sfmhip_synchronize(sfmhip_ctx* ctx);
 /* Measurement aid (no reference counterpart): with timing enabled every kNN launch sequence on this context is
  * bracketed by HIP events on its stream.  sfmhip_match_kernel_ms synchronises and returns, averaged over the calls
  * since the last query (at most 64): [0] the kNN kernel itself (knn2_i8 / exact f32 / hamming2), [1] merge + re-score,
- * [2] number of calls averaged, [3] reserved (0). */
+ * [2] number of calls averaged, [3] reserved (0).  The same switch turns on the per-phase events of the bundle
+ * adjustment loop (sfmhip_ba_phase_ms). */
 int  sfmhip_set_kernel_timing(sfmhip_ctx* ctx, int enable);
 int  sfmhip_match_kernel_ms(sfmhip_ctx* ctx, double out_ms[4]);
 const char* sfmhip_last_error(sfmhip_ctx* ctx);
