@@ -239,3 +239,22 @@ def test_non_chain_tracks_take_the_dense_solver_and_match_oracle(ctx):
     assert abs(s["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
     K, ext, pts = pb.params()
     assert np.abs(ext - exto).max() <= 1e-7 and np.abs(pts - ptso).max() <= 1e-6
+
+
+def test_phase_timing_is_opt_in(ctx):
+    """sfmhip_ba_phase_ms reports only while sfmhip_set_kernel_timing is on (the events cost ~27 us per iteration)."""
+    sc = synth.ba_scene(120, 30000)
+    pb = ctx.ba_create(*_args(sc))
+    pb.iterate(3)
+    assert not any(pb.phase_ms()[:7])
+    ctx.set_kernel_timing(True)
+    try:
+        pb.iterate(3)
+        ph = pb.phase_ms()
+    finally:
+        ctx.set_kernel_timing(False)
+    assert all(v > 0 for v in ph[:4]) and abs(ph[0] + ph[1] + ph[2] - ph[3]) <= 1e-6 * ph[3]    # float32 event times
+    assert ph[6] > 0 and ph[7] > 0          # four dissection segments: the forward kernel is timed, the factor has blocks
+    pb.iterate(2)
+    assert not any(pb.phase_ms()[:7])       # "of the last iterate call"
+    pb.close()
