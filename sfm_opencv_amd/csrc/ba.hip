@@ -405,7 +405,7 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     BADev P = make_dev(h, radius);
-    hipLaunchKernelGGL(ba_camstep_kernel, dim3(1), dim3(256), 0, st, P, h->d_cam2);
+    hipLaunchKernelGGL(ba_camstep_kernel, dim3(1 + ceil_div(h->nc, 256)), dim3(256), 0, st, P, h->d_cam2);     // block 0: the step; the others: candidate rotation blocks
     hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P);
     hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4);
     SFM_HIP_TRY(ctx, hipGetLastError());

@@ -773,6 +773,24 @@ __global__ void ba_scale_kernel(const double* __restrict__ colsq, double* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __restrict__ out2)
 {
+#pragma clang fp contract(off)          // x + (-y * scale) must round the same way in block 0 and in the other blocks
+    if (blockIdx.x > 0) {
+        // blocks 1..: the candidate cameras' rotation blocks (what ba_campre_kernel computes), each thread from its own copy
+        // of the candidate extrinsics (same arithmetic as block 0's, so nothing waits for block 0)
+        const int c = (blockIdx.x - 1) * 256 + threadIdx.x;
+        if (c >= P.nc) return;
+        const int co = cam_off(P, c);
+        double e[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double x = P.ext[6 * c + j];
+            double d = 0.0;
+            if (co >= 0) d = -P.y[co + j] * P.scale_c[co + j];
+            e[j] = x + d;
+        }
+        campre_one(e, const_cast<double*>(P.campre_c) + 36 * (size_t)c);
+        return;
+    }
     __shared__ double red[4][2];
     double dn = 0.0, xn = 0.0;
     for (int i = threadIdx.x; i < 6 * P.nc + 4; i += 256) {
@@ -814,8 +832,6 @@ __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __rest
             P.scal[1] = m;
         }
     }
-    // the candidate cameras' rotation blocks (what ba_campre_kernel computes), in the same launch
-    for (int c = threadIdx.x; c < P.nc; c += 256) campre_one(P.extc + 6 * c, const_cast<double*>(P.campre_c) + 36 * (size_t)c);
 }
 
 // The scalars the host needs to accept or reject the step, gathered into pinned host memory by one wave, then a sequence
