@@ -249,6 +249,7 @@ static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = fal
     P.part_pt = h->d_part_pt; P.part_cam = h->d_part_cam; P.part_back = h->d_part_back;
     P.y = h->d_y;
     P.radius = radius; P.min_diag = h->o.min_lm_diagonal; P.max_diag = h->o.max_lm_diagonal;
+    { static const int plain = getenv("SFMHIP_EXP_XCD_PLAIN") ? 1 : 0; P.xcd_plain = plain; }
     if (at_candidate) {
         P.K = h->d_Kc; P.ext = h->d_extc; P.pts = h->d_ptsc; P.Kc = h->d_K; P.extc = h->d_ext; P.ptsc = h->d_pts;
         P.campre = h->d_campre_c; P.campre_c = h->d_campre;

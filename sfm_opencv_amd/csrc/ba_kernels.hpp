@@ -46,6 +46,7 @@ struct BADev {
     // solution of the reduced system (scaled coordinates, y; step = -y)
     const double* y;
     double radius, min_diag, max_diag;
+    int xcd_plain;        // measurement knob (SFMHIP_EXP_XCD_PLAIN): 1 = work item = workgroup index, no XCD-aware order
 };
 
 #define SCAL_COST 0
@@ -436,10 +437,10 @@ __host__ __device__ constexpr int cam_part_slot(int part, int j)
 // gives every XCD one contiguous range of items: consecutive cameras (and camera pairs) share most of their points, so
 // each XCD's L2 serves a point's record to all the observations of it instead of every observation fetching it over the
 // fabric (the linearisation moved ~0.5 GB per pass for 90 MB of distinct data and ran at the fabric's rate).
-__device__ __forceinline__ int xcd_item(int n_items)
+__device__ __forceinline__ int xcd_item(int n_items, int plain)
 {
     const int L = blockIdx.x, per = (gridDim.x + 7) >> 3;           // gridDim.x is a multiple of 8
-    const int v = (L & 7) * per + (L >> 3);
+    const int v = plain ? L : (L & 7) * per + (L >> 3);
     return v < n_items ? v : -1;
 }
 
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
     __shared__ double red[4][CAMACC];
     // item = (camera * cam_split + slice) * parts + part: the two parts of a slice sit next to each other
     const int parts = P.fixK ? 1 : 2;
-    const int v = xcd_item(P.nc * P.cam_split * parts);
+    const int v = xcd_item(P.nc * P.cam_split * parts, P.xcd_plain);
     if (v < 0) return;
     const int part = v % parts, cs = v / parts, c = cs / P.cam_split, sp_i = cs % P.cam_split;
     if (part == 0) ba_camera_body<0>(P, red, c, sp_i); else ba_camera_body<1>(P, red, c, sp_i);
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
                                                        const int4* __restrict__ items, double* __restrict__ part)
 {
     const int lane = threadIdx.x & 63;
-    const int item = xcd_item((n_chunk + 3) >> 2);                   // four consecutive chunks per workgroup
+    const int item = xcd_item((n_chunk + 3) >> 2, P.xcd_plain);                   // four consecutive chunks per workgroup
     if (item < 0) return;
     const int chunk = item * 4 + (threadIdx.x >> 6);
     if (chunk >= n_chunk) return;
