@@ -156,7 +156,7 @@ def main():
         gemm = dict(kernel="distmat_i8_kernel<4>", workload="10000x10000x128 float32 distance matrix", ms=ms,
                     bound="hbm", achieved=alg / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=alg,
-                    traffic=4.197e8)      # TCC WRITE_SIZE + 2 x FETCH_SIZE per launch, profiles/r01_traffic_pmc.md
+                    traffic=4.378e8)      # TCC WRITE_SIZE + 2 x FETCH_SIZE per launch, profiles/r01_traffic_pmc.md
         del out, qs, ts
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
@@ -207,10 +207,10 @@ def main():
             ops = 2.0 * n_desc * n_desc * 128 * n_pairs_l       # 2 * nq * nt * dim per pair
             # TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch, separate --pmc passes of this command at
             # N=1 / C4 (profiles/r01_traffic_pmc.md); not collectable from inside the process
-            traffic = 1.092e9 if (world == 1 and args.config == "C4") else None
+            traffic = 2.977e8 if (world == 1 and args.config == "C4") else None
             roof = {"kernel": "knn2_i8_kernel<4>", "bound": "mfma", "achieved": ops / (knn_kernel_ms * 1e-3) / 1e12,
                     "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ops / (knn_kernel_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                    "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; operands are 255 MB, each XCD's L2 fetches its own copy)", "algorithmic_ops": ops, "avg_launch_ms": knn_kernel_ms, "launches_timed": int(knn_calls),
+                    "traffic": traffic, "traffic_unit": "bytes per launch, L2 fabric side: 2 x FETCH_SIZE + WRITE_SIZE (operands 255 MB + 32 MB of partial keys; 1,092 MB before the pair -> XCD mapping)", "algorithmic_ops": ops, "avg_launch_ms": knn_kernel_ms, "launches_timed": int(knn_calls),
                     "merge_rescore_ms": knn_merge_ms,
                     "note": "one launch = all chain pairs of this rank; peak = dense int8 MFMA at 2.4 GHz (measured sustained "
                             "4.2 POP/s, experiments/mfma_i8_bench.hip); the top-2 epilogue (3 VALU ops per distance) bounds "
