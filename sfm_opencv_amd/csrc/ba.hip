@@ -207,6 +207,7 @@ struct sfmhip_ba {
     int n_diag_blk = 0;            // camera pairs (a, a): a point seen twice by one camera
     bool solver_damps = false; double damp_radius = 0.0;    // the next enqueue_solve applies the LM damping inside its kernels
     bool build_timed = false;      // the pending build recorded its events (timing can be switched between launches)
+    bool publish_in_back = false, published = false;   // ba_loop asks enqueue_back to publish the step scalars from its reduction kernel
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
@@ -408,7 +409,12 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     BADev P = make_dev(h, radius);
     hipLaunchKernelGGL(ba_camstep_kernel, dim3(1 + ceil_div(h->nc, 256)), dim3(256), 0, st, P, h->d_cam2);     // block 0: the step; the others: candidate rotation blocks
     hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4);
+    // single rank: the reduction also publishes the decision scalars (ba_loop then skips ba_publish_kernel)
+    const bool fuse_publish = !h->ar_fn && h->publish_in_back;
+    const double* d_scal = h->d_msg + (size_t)h->npad * h->npad + 3 * (size_t)h->npad;
+    hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4,
+                       d_scal, h->d_cam2, h->d_err, fuse_publish ? h->h_scal : (double*)nullptr, fuse_publish ? ++h->pub_seq : 0ull);
+    h->published = fuse_publish;
     SFM_HIP_TRY(ctx, hipGetLastError());
     return call_allreduce(h, h->d_back4, 4);
 }
@@ -637,12 +643,16 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
         rc = enqueue_solve(h); if (rc) return rc;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
-        rc = enqueue_back(h, h->radius); if (rc) return rc;
+        h->publish_in_back = true;
+        rc = enqueue_back(h, h->radius); h->publish_in_back = false; if (rc) return rc;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
         // one wave gathers the nine scalars into pinned host memory and bumps a sequence number the host polls; it also
         // re-arms the error flag.  The next build's zero-fill does not depend on the decision: it runs while the host decides.
-        const unsigned long long seq = ++h->pub_seq;
-        hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
+        unsigned long long seq = h->pub_seq;
+        if (!h->published) {
+            seq = ++h->pub_seq;
+            hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
+        }
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
         if (!h->ar_fn) {
             SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));

@@ -979,7 +979,11 @@ __global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P)
 }
 
 // out4 = sum over blocks of part_back
-__global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out4)
+// With host_out != nullptr (single rank: nothing is all-reduced in between) the block also publishes the decision scalars,
+// i.e. does ba_publish_kernel's job in the same launch.
+__global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out4,
+                                                             const double* __restrict__ scal2, const double* __restrict__ cam2, int* __restrict__ err,
+                                                             double* __restrict__ host_out, unsigned long long seq)
 {
     __shared__ double red[4][4];
     double acc[4] = { 0, 0, 0, 0 };
@@ -992,7 +996,20 @@ __global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = acc[i];
     __syncthreads();
-    if (threadIdx.x < 4) out4[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 4) {
+        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out4[threadIdx.x] = v;
+        if (host_out) host_out[2 + threadIdx.x] = v;
+    }
+    if (host_out) {
+        const int l = threadIdx.x;
+        if (l >= 64 && l < 66) host_out[l - 64] = scal2[l - 64];
+        else if (l >= 66 && l < 68) host_out[6 + l - 66] = cam2[l - 66];
+        else if (l == 68) { host_out[8] = (double)*err; *err = 0; }
+        __threadfence_system();
+        __syncthreads();
+        if (l == 0) __hip_atomic_store((unsigned long long*)(host_out + 15), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // cost only at the current parameters (used for |x| bookkeeping at start-up): not needed separately --
