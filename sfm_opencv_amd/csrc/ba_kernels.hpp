@@ -336,12 +336,14 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
     double acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    // per-point results, stored after the block below through a per-wave LDS transposition (see there)
+    double Vi[6] = { 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 }, WK[12], cs[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 12; ++i) WK[i] = 0.0;
     if (p < P.np) {
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
-        double V[6] = { 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 }, WK[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) WK[i] = 0.0;
+        double V[6] = { 0, 0, 0, 0, 0, 0 };
         double cost = 0.0;
         const int s0 = P.pt_start[p], s1 = P.pt_start[p + 1];
         for (int k = s0; k < s1; ++k) {
@@ -366,19 +368,11 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
                 for (int j = 0; j < 3; ++j) ACC2(WK[3 * i + j], o.EK[0][i], o.F[0][j], o.EK[1][i], o.F[1][j]);
 #undef ACC2
         }
-        const double cs[3] = { V[0], V[2], V[5] };
-        P.colsq_p[3 * p] = cs[0]; P.colsq_p[3 * p + 1] = cs[1]; P.colsq_p[3 * p + 2] = cs[2];
+        cs[0] = V[0]; cs[1] = V[2]; cs[2] = V[5];
         V[0] += fmin(fmax(cs[0], P.min_diag), P.max_diag) / P.radius;
         V[2] += fmin(fmax(cs[1], P.min_diag), P.max_diag) / P.radius;
         V[5] += fmin(fmax(cs[2], P.min_diag), P.max_diag) / P.radius;
-        double Vi[6];
         if (!inv3_spd(V, Vi)) *err = 1;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) P.Vinv[6 * (size_t)p + i] = Vi[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) P.bp[3 * (size_t)p + i] = b[i];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) P.WK[12 * (size_t)p + i] = WK[i];
         // T = WK Vi (4x3); SKK = T WK' ; gK = T b
         double T[12];
 #pragma unroll
@@ -395,6 +389,39 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
         acc[15] = fmax(fabs(b[0] * rcp_nr(sp[0])), fmax(fabs(b[1] * rcp_nr(sp[1])), fabs(b[2] * rcp_nr(sp[2]))));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        // Stores through a per-wave LDS transposition: a wave's 64 records of an array are one contiguous span, written as
+        // whole 16-byte (8-byte) pieces lane after lane.  Stored straight from the registers, every instruction scattered
+        // 16 B per lane at a 48/96-byte stride: 13 partial-line requests per point at the L2, ~4M per launch.
+        __shared__ double stage[4][64 * 13];
+        double* buf = stage[wave];
+        const int first = blockIdx.x * 256 + wave * 64;               // this wave's first point
+        const int npts = min(64, P.np - first);                        // records of this wave that exist (<= 0: none)
+        // W_K: 12 doubles per point = 384 double2 per wave
+#pragma unroll
+        for (int i = 0; i < 12; ++i) buf[lane * 13 + i] = WK[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int j = lane + 64 * i, pt = j / 6, pr = j - 6 * pt;
+            if (pt < npts) *(double2*)(P.WK + 12 * (size_t)first + 2 * j) = make_double2(buf[pt * 13 + 2 * pr], buf[pt * 13 + 2 * pr + 1]);
+        }
+        // V^-1: 6 doubles per point = 192 double2 per wave
+#pragma unroll
+        for (int i = 0; i < 6; ++i) buf[lane * 7 + i] = Vi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = lane + 64 * i, pt = j / 3, pr = j - 3 * pt;
+            if (pt < npts) *(double2*)(P.Vinv + 6 * (size_t)first + 2 * j) = make_double2(buf[pt * 7 + 2 * pr], buf[pt * 7 + 2 * pr + 1]);
+        }
+        // b_p and the raw column norms: 3 doubles per point, already contiguous as [point][3]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { buf[lane * 3 + i] = b[i]; buf[256 + lane * 3 + i] = cs[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = lane + 64 * i;
+            if (f < 3 * npts) { P.bp[3 * (size_t)first + f] = buf[f]; P.colsq_p[3 * (size_t)first + f] = buf[256 + f]; }
+        }
+    }
     {
         double v15[15];
 #pragma unroll
