@@ -171,7 +171,7 @@ struct sfmhip_ba {
     double *d_K0 = nullptr, *d_ext0 = nullptr, *d_pts0 = nullptr;
     double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera R and dR/dw (36 doubles), current / candidate
     // structure
-    int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_pt = nullptr;
+    int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_pt = nullptr, *d_blk_crange = nullptr;
     int *d_blk_cam = nullptr, *d_blk_chunk = nullptr; int4 *d_items = nullptr, *d_chunk_desc = nullptr; int nchunk = 0; double* d_part_schur = nullptr;
     int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
     std::vector<int> host_blk_cam;
@@ -240,7 +240,7 @@ static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = fal
     P.huber_a = h->o.huber_delta;
     P.K = h->d_K; P.ext = h->d_ext; P.pts = h->d_pts; P.Kc = h->d_Kc; P.extc = h->d_extc; P.ptsc = h->d_ptsc;
     P.pt_start = h->d_pt_start; P.ocam = h->d_ocam; P.ouv = h->d_ouv;
-    P.cam_start = h->d_cam_start; P.cam_pt = h->d_cam_pt; P.cam_uv = h->d_cam_uv; P.opt = h->d_opt;
+    P.cam_start = h->d_cam_start; P.cam_pt = h->d_cam_pt; P.cam_uv = h->d_cam_uv; P.opt = h->d_opt; P.blk_crange = h->d_blk_crange;
     P.cam_pos = h->d_cam_pos; P.posmask = h->d_posmask;
     P.campre = h->d_campre; P.campre_c = h->d_campre_c;
     P.scale_c = h->d_scale_c; P.scale_p = h->d_scale_p;
@@ -863,6 +863,16 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_pt_start, pt_start.data(), pt_start.size())); TRY_RC(dupload(h, &h->d_ocam, ocam.data(), ocam.size()));
     TRY_RC(dupload(h, &h->d_opt, opt.data(), opt.size())); TRY_RC(dupload(h, &h->d_ouv, ouv.data(), ouv.size()));
     TRY_RC(dupload(h, &h->d_cam_start, cam_start.data(), cam_start.size())); TRY_RC(dupload(h, &h->d_cam_pt, cam_pt.data(), cam_pt.size()));
+    {   // camera range of every block of 256 points (K_back stages those cameras in LDS)
+        std::vector<int> crange(2 * (size_t)h->n_pt_blocks);
+        for (int b = 0; b < h->n_pt_blocks; ++b) {
+            int lo = INT_MAX, hi = -1;
+            const int p_end = std::min(n_pt, (b + 1) * 256);
+            for (int q = pt_start[std::min(n_pt, b * 256)]; q < pt_start[p_end]; ++q) { lo = std::min(lo, ocam[q]); hi = std::max(hi, ocam[q]); }
+            crange[2 * (size_t)b] = lo; crange[2 * (size_t)b + 1] = hi;
+        }
+        TRY_RC(dupload(h, &h->d_blk_crange, crange.data(), crange.size()));
+    }
     TRY_RC(dupload(h, &h->d_cam_uv, cam_uv.data(), cam_uv.size()));
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_chunk, blk_chunk.data(), blk_chunk.size()));
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size())); TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));

@@ -27,6 +27,7 @@ struct BADev {
     // observations ordered by point
     const int* pt_start; const int* ocam; const double* ouv;
     // per-camera lists (indices into the by-point ordering) and their points
+    const int* blk_crange;   // per block of 256 points (storage order): lowest and highest camera among their observations
     const int* cam_start; const int* cam_pt; const double* cam_uv; const int* opt;   // cam_pt / cam_uv: point slot and pixel of each observation, in camera order
     // layout of the reduced system: position of camera c's 6 columns (-1 = constant camera), koff = intrinsics;
     // posmask[i] = 1 for a real parameter, 0 for a padding slot (segments are padded to whole 32-blocks)
@@ -961,20 +962,11 @@ __global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P)
 {
     __shared__ double red[4][4];
     __shared__ __attribute__((aligned(16))) double cam[BACK_NCL][BACK_REC];
-    __shared__ int crange[2][4];
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[4] = { 0, 0, 0, 0 };
-    // camera range of the block's points (a point's observations are stored in ascending camera order only if the caller
-    // listed them so: take min / max over all of them)
-    int cmin = INT_MAX, cmax = -1;
-    if (p < P.np) for (int k = P.pt_start[p]; k < P.pt_start[p + 1]; ++k) { const int c = P.ocam[k]; cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int a = __shfl_xor(cmin, off), b = __shfl_xor(cmax, off); cmin = a < cmin ? a : cmin; cmax = b > cmax ? b : cmax; }
-    if (lane == 0) { crange[0][wave] = cmin; crange[1][wave] = cmax; }
-    __syncthreads();
-    cmin = min(min(crange[0][0], crange[0][1]), min(crange[0][2], crange[0][3]));
-    cmax = max(max(crange[1][0], crange[1][1]), max(crange[1][2], crange[1][3]));
+    // camera range of the block's points: fixed by the observation lists, tabulated when the problem is created
+    const int cmin = P.blk_crange[2 * blockIdx.x], cmax = P.blk_crange[2 * blockIdx.x + 1];
     const bool staged = cmax >= cmin && cmax - cmin < BACK_NCL;          // block-uniform
     if (staged) {
         const int n = (cmax - cmin + 1) * BACK_REC;
