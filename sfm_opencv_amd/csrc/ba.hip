@@ -169,7 +169,7 @@ struct sfmhip_ba {
     double *d_K = nullptr, *d_ext = nullptr, *d_pts = nullptr;
     double *d_Kc = nullptr, *d_extc = nullptr, *d_ptsc = nullptr;
     double *d_K0 = nullptr, *d_ext0 = nullptr, *d_pts0 = nullptr;
-    double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera R and dR/dw (36 doubles), current / candidate
+    double *d_campre = nullptr, *d_campre_c = nullptr;     // per-camera rotation blocks (CAMPRE doubles), current / candidate
     // structure
     int *d_pt_start = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_cam_start = nullptr, *d_cam_pt = nullptr, *d_blk_crange = nullptr;
     int *d_blk_cam = nullptr, *d_blk_chunk = nullptr; int4 *d_items = nullptr, *d_chunk_desc = nullptr; int nchunk = 0; double* d_part_schur = nullptr;
@@ -878,7 +878,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size())); TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));
     TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));
     TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
-    TRY_RC(dalloc(h, &h->d_campre, 36 * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, 36 * (size_t)n_cam));
+    TRY_RC(dalloc(h, &h->d_campre, CAMPRE * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, CAMPRE * (size_t)n_cam));
     TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_seg_blk, 16));
     TRY_RC(dalloc(h, &h->d_prow_start, (size_t)h->npad_max / NB + 2)); TRY_RC(dalloc(h, &h->d_prow, ((size_t)h->npad_max / NB + 1) * SRMAX + 1));
     TRY_RC(dalloc(h, &h->d_Vinv, 6 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_bp, 3 * (size_t)n_pt));

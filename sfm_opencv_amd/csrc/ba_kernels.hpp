@@ -32,7 +32,7 @@ struct BADev {
     // layout of the reduced system: position of camera c's 6 columns (-1 = constant camera), koff = intrinsics;
     // posmask[i] = 1 for a real parameter, 0 for a padding slot (segments are padded to whole 32-blocks)
     const int* cam_pos; const int* posmask;
-    // per-camera rotation matrix and its angle-axis derivatives (36 doubles: R, dR/dw0, dR/dw1, dR/dw2), current / candidate
+    // per-camera rotation block (CAMPRE doubles: R, the three derivative vectors c_m, branch flag -- see campre_one), current / candidate
     const double* campre; const double* campre_c;
     // column scaling (cam side: npad entries; points: 3 np)
     const double* scale_c; const double* scale_p;
@@ -104,9 +104,16 @@ __device__ __forceinline__ void rotate_with_derivs(const double* __restrict__ e,
     }
 }
 
-// pre[36] per camera: R row-major (9), then dR/dw_m row-major (9 each, m = 0..2)
+// Per-camera rotation block, CAMPRE = 20 doubles: R row-major (9) | c_0, c_1, c_2 (9) | flag | pad.
+// d(R(w) X)/dw_m = (dR/dw_m) X = c_m x (R X) with [c_m]x = (dR/dw_m) R' -- an identity of the exponential map, so the three
+// 3x3 derivative matrices (27 doubles, 27 fma per observation) shrink to three vectors (18 mul/fma) and the block fits the
+// scalar registers next to K, t and the column scales.  ceres::AngleAxisRotatePoint switches to the first-order formula
+// p = X + w x X for theta^2 <= DBL_EPSILON, whose derivative is e_m x X exactly: there flag = 1, c_m = e_m, and the kernels
+// take the cross product with X instead of R X (obs_linearize), which reproduces that branch bit for bit.
+#define CAMPRE 20
 __device__ __forceinline__ void campre_one(const double* __restrict__ e, double* __restrict__ o)
 {
+    double R[3][3], dR[3][3][3];            // dR[m][k][col] = d R[k][col] / d w_m
 #pragma unroll
     for (int col = 0; col < 3; ++col) {
         const double X[3] = { col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0 };
@@ -114,17 +121,36 @@ __device__ __forceinline__ void campre_one(const double* __restrict__ e, double*
         rotate_with_derivs(e, X, p, dpw);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            o[3 * k + col] = p[k];
+            R[k][col] = p[k];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) o[9 + 9 * m + 3 * k + col] = dpw[m][k];
+            for (int m = 0; m < 3; ++m) dR[m][k][col] = dpw[m][k];
         }
     }
+    const bool small = !(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] > DBL_EPSILON);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int col = 0; col < 3; ++col) o[3 * k + col] = R[k][col];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        // M = dR_m R' (skew-symmetric up to rounding: take the antisymmetric part)
+        double M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a][b] = dR[m][a][0] * R[b][0] + dR[m][a][1] * R[b][1] + dR[m][a][2] * R[b][2];
+        o[9 + 3 * m + 0] = small ? (m == 0 ? 1.0 : 0.0) : 0.5 * (M[2][1] - M[1][2]);
+        o[9 + 3 * m + 1] = small ? (m == 1 ? 1.0 : 0.0) : 0.5 * (M[0][2] - M[2][0]);
+        o[9 + 3 * m + 2] = small ? (m == 2 ? 1.0 : 0.0) : 0.5 * (M[1][0] - M[0][1]);
+    }
+    o[18] = small ? 1.0 : 0.0;
+    o[19] = 0.0;
 }
 
 __global__ void ba_campre_kernel(const double* __restrict__ ext, int nc, double* __restrict__ pre)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nc) campre_one(ext + 6 * c, pre + 36 * (size_t)c);
+    if (c < nc) campre_one(ext + 6 * c, pre + CAMPRE * (size_t)c);
 }
 
 // 1/sqrt(d) and 1/d by the hardware seed + two Newton steps (~1 ulp): 7 / 5 dependent ops, where sqrt() and the IEEE
@@ -158,7 +184,7 @@ __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, doub
     }
 }
 
-// cost only: 1/2 rho(|r|^2); pre = the camera's 36-double block (only R is read), t = its translation
+// cost only: 1/2 rho(|r|^2); pre = the camera's rotation block (only R is read), t = its translation
 __device__ __forceinline__ double obs_cost(const double* __restrict__ K4, const double* __restrict__ pre, const double* __restrict__ t,
                                            const double X[3], double u, double v, double huber_a)
 {
@@ -183,9 +209,9 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) R[i][j] = pre[3 * i + j];
-    double p[3];
+    double q[3], p[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = R[k][0] * X[0] + R[k][1] * X[1] + R[k][2] * X[2] + t[k];
+    for (int k = 0; k < 3; ++k) { q[k] = R[k][0] * X[0] + R[k][1] * X[1] + R[k][2] * X[2]; p[k] = q[k] + t[k]; }
     const double iz = rcp_nr(p[2]);
     const double x = p[0] * iz, y = p[1] * iz;
     double r0 = K4[0] * x + K4[2] - u;
@@ -205,12 +231,15 @@ __device__ __forceinline__ void obs_linearize(const double* __restrict__ K4, con
         for (int j = 0; j < 4; ++j) { o.EK[0][j] = 0.0; o.EK[1][j] = 0.0; }
     }
     if (sc) {
+        // dp_m = c_m x (R X), or e_m x X in the first-order branch of the angle-axis formula (campre_one)
+        const bool first_order = pre[18] != 0.0;
+        const double g0 = first_order ? X[0] : q[0], g1 = first_order ? X[1] : q[1], g2 = first_order ? X[2] : q[2];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            const double* d = pre + 9 + 9 * m;        // dR/dw_m
-            const double dp0 = d[0] * X[0] + d[1] * X[1] + d[2] * X[2];
-            const double dp1 = d[3] * X[0] + d[4] * X[1] + d[5] * X[2];
-            const double dp2 = d[6] * X[0] + d[7] * X[1] + d[8] * X[2];
+            const double* cm = pre + 9 + 3 * m;
+            const double dp0 = cm[1] * g2 - cm[2] * g1;
+            const double dp1 = cm[2] * g0 - cm[0] * g2;
+            const double dp2 = cm[0] * g1 - cm[1] * g0;
             o.Ec[0][m] = (a00 * dp0 + a02 * dp2) * sc[m];
             o.Ec[1][m] = (a11 * dp1 + a12 * dp2) * sc[m];
         }
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
         for (int k = s0; k < s1; ++k) {
             const int c = P.ocam[k];
             ObsLin o;
-            obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
+            obs_linearize(P.K, P.campre + CAMPRE * (size_t)c, P.ext + 6 * c + 3, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a,
                           P.fixK ? nullptr : P.scale_c + P.koff, nullptr, sp, o);
             cost += 0.5 * o.rho0;
             // two chained fma per sum (x*y + z*w + acc would be mul, fma, add)
@@ -493,7 +522,7 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
         const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
         const double spp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
         ObsLin o;
-        obs_linearize(P.K, P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, X, P.cam_uv[2 * (size_t)q], P.cam_uv[2 * (size_t)q + 1], P.huber_a, sK, sc, spp, o);
+        obs_linearize(P.K, P.campre + CAMPRE * (size_t)c, P.ext + 6 * c + 3, X, P.cam_uv[2 * (size_t)q], P.cam_uv[2 * (size_t)q + 1], P.huber_a, sK, sc, spp, o);
         double Vi[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
@@ -708,7 +737,7 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
         double G[2][3], Ea[2][6];
         {
             ObsLin o;
-            obs_linearize(P.K, P.campre + 36 * (size_t)ca, P.ext + 6 * ca + 3, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
+            obs_linearize(P.K, P.campre + CAMPRE * (size_t)ca, P.ext + 6 * ca + 3, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
             symv3(Vi, o.F[0], G[0]);
             symv3(Vi, o.F[1], G[1]);
 #pragma unroll
@@ -717,7 +746,7 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
         double N0[6], N1[6];
         {
             ObsLin o;
-            obs_linearize(P.K, P.campre + 36 * (size_t)cb, P.ext + 6 * cb + 3, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
+            obs_linearize(P.K, P.campre + CAMPRE * (size_t)cb, P.ext + 6 * cb + 3, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
             const double m00 = G[0][0] * o.F[0][0] + G[0][1] * o.F[0][1] + G[0][2] * o.F[0][2];
             const double m01 = G[0][0] * o.F[1][0] + G[0][1] * o.F[1][1] + G[0][2] * o.F[1][2];
             const double m10 = G[1][0] * o.F[0][0] + G[1][1] * o.F[0][1] + G[1][2] * o.F[0][2];
@@ -817,7 +846,7 @@ __global__ __launch_bounds__(256) void ba_camstep_kernel(BADev P, double* __rest
             if (co >= 0) d = -P.y[co + j] * P.scale_c[co + j];
             e[j] = x + d;
         }
-        campre_one(e, const_cast<double*>(P.campre_c) + 36 * (size_t)c);
+        campre_one(e, const_cast<double*>(P.campre_c) + CAMPRE * (size_t)c);
         return;
     }
     __shared__ double red[4][2];
@@ -886,7 +915,7 @@ __global__ void ba_publish_kernel(const double* __restrict__ scal2, const double
 // ------------------------------------------------------------------------------------------------
 #define BACK_NCL 24       // cameras of a block's points staged in LDS (points are stored sorted by camera set: a block of 256
                           // consecutive points sees a handful of neighbouring cameras); wider blocks read the cameras from global
-#define BACK_REC 92       // doubles per staged camera: R/dR (36) | t (3) | candidate R/dR (36) | candidate t (3) | scale (6) | y (6) | pad
+#define BACK_REC 60       // doubles per staged camera: rotation block (20) | t (3) | candidate block (20) | candidate t (3) | scale (6) | y (6) | pad
 
 struct BackCam { const double *pre, *t, *pre_c, *t_c, *sc, *y; };     // one camera's inputs of K_back (LDS record or global arrays)
 
@@ -948,13 +977,13 @@ __device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_a
 // fills one camera record (BACK_REC doubles) from the global arrays
 __device__ __forceinline__ double back_rec_value(const BADev& P, int c, int f)
 {
-    if (f < 36) return P.campre[36 * (size_t)c + f];
-    if (f < 39) return P.ext[6 * c + 3 + (f - 36)];
-    if (f < 75) return P.campre_c[36 * (size_t)c + (f - 39)];
-    if (f < 78) return P.extc[6 * c + 3 + (f - 75)];
+    if (f < 20) return P.campre[CAMPRE * (size_t)c + f];
+    if (f < 23) return P.ext[6 * c + 3 + (f - 20)];
+    if (f < 43) return P.campre_c[CAMPRE * (size_t)c + (f - 23)];
+    if (f < 46) return P.extc[6 * c + 3 + (f - 43)];
     const int co = cam_off(P, c);
-    if (f < 84) return co >= 0 ? P.scale_c[co + (f - 78)] : 0.0;
-    if (f < 90) return co >= 0 ? P.y[co + (f - 84)] : 0.0;
+    if (f < 52) return co >= 0 ? P.scale_c[co + (f - 46)] : 0.0;
+    if (f < 58) return co >= 0 ? P.y[co + (f - 52)] : 0.0;
     return 0.0;
 }
 
@@ -977,11 +1006,11 @@ __global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P)
         if (staged) {
             ba_back_point(P, p, [&](int c) {
                 const double* r = &cam[c - cmin][0];
-                return BackCam{ r, r + 36, r + 39, r + 75, r + 78, r + 84 }; }, acc);
+                return BackCam{ r, r + 20, r + 23, r + 43, r + 46, r + 52 }; }, acc);
         } else {            // the block's points span too many cameras: straight from the global arrays
             ba_back_point(P, p, [&](int c) {
                 const int co = cam_off(P, c);
-                return BackCam{ P.campre + 36 * (size_t)c, P.ext + 6 * c + 3, P.campre_c + 36 * (size_t)c, P.extc + 6 * c + 3,
+                return BackCam{ P.campre + CAMPRE * (size_t)c, P.ext + 6 * c + 3, P.campre_c + CAMPRE * (size_t)c, P.extc + 6 * c + 3,
                                 P.scale_c + (co < 0 ? 0 : co), P.y + (co < 0 ? 0 : co) }; }, acc);
         }
     }

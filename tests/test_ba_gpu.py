@@ -283,3 +283,21 @@ def test_randomised_shapes_follow_oracle(ctx, seed):
     if kw["fix_first_camera"]:
         assert np.abs(ext - exto).max() <= 1e-6 * 10.0 and np.abs(K - Ko).max() <= 1e-6 * 3000.0, (n_cam, n_pt, max_len, kw)
         assert np.quantile(np.abs(pts - ptso).max(axis=1), 0.99) <= 1e-6 * 10.0, (n_cam, n_pt, max_len, kw)
+
+
+@pytest.mark.parametrize("omega", [(0.0, 0.0, 0.0), (6e-9, -3e-9, 2e-9), (3e-8, 5e-8, -4e-8), (2e-5, -1e-5, 3e-5)])
+def test_angle_axis_first_order_branch_and_tiny_angles(ctx, omega):
+    """ceres::AngleAxisRotatePoint switches to p = X + w x X for theta^2 <= DBL_EPSILON; the kernels carry that branch as a
+    per-camera flag (derivative e_m x X) and otherwise form d(RX)/dw_m = c_m x (R X): free cameras exactly at, just below,
+    just above the switch and at a tiny angle must give the oracle's reduced system."""
+    sc = synth.ba_scene(7, 400, outlier_frac=0.0)
+    ext = sc["ext0"].copy()
+    ext[2, :3] = omega; ext[5, :3] = np.array(omega) * -0.5
+    args = (sc["K0"], ext, sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    for kw in (dict(), dict(fix_first_camera=0)):
+        pb = ctx.ba_create(*args, opts=ctx.ba_options(**kw))
+        S, rhs, cost = pb.reduced_system(1e4)
+        So, rhso, costo = orc.ba_reduced_system(*args, 1e4, opts=orc.ba_default_options(**kw))
+        pb.close()
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9

@@ -99,13 +99,13 @@ def test_c4_bundle_adjustment_full_size(ctx):
     s2 = pb2.iterate(12)
     # (different fp64 summation orders through 12 LM iterations: 1e-7 on the cost, 1e-9 on the cameras; a point's update is
     #  V_p^-1 (...) with cond(V_p) up to ~1e10 for two-view points at a narrow baseline or with an outlier pixel, so the
-    #  bulk of the points must agree to 1e-9 and the worst-conditioned few to 1e-3)
+    #  bulk of the points must agree to 1e-9 (median 1e-10) and the worst-conditioned few to 1e-3)
     assert abs(s2["final_cost"] - costs[-1]) <= 1e-7 * costs[-1]
     K2, ext2, pts2 = pb2.params()
     dp = np.abs(pts2 - pts[pperm]).max(axis=1)
     q = np.quantile(dp, [0.5, 0.99, 0.999, 1.0])
     assert np.abs(ext2 - ext).max() <= 1e-9 and np.abs(K2 - K).max() <= 1e-9 * np.abs(K).max()
-    assert q[0] <= 1e-11 and q[1] <= 1e-9 and q[3] <= 1e-3, f"point differences, quantiles 0.5/0.99/0.999/1: {q}"
+    assert q[0] <= 1e-10 and q[1] <= 1e-9 and q[3] <= 1e-3, f"point differences, quantiles 0.5/0.99/0.999/1: {q}"
     # (4) partial systems over 4 point shards add up to the full one (the multi-GPU contract, radius < 0 form)
     #     (column scaling off: each shard would otherwise scale by its own column norms)
     o = ctx.ba_options(jacobi_scaling=0)
