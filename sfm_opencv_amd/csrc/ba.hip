@@ -883,7 +883,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dalloc(h, &h->d_prow_start, (size_t)h->npad_max / NB + 2)); TRY_RC(dalloc(h, &h->d_prow, ((size_t)h->npad_max / NB + 1) * SRMAX + 1));
     TRY_RC(dalloc(h, &h->d_Vinv, 6 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_bp, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_WK, 12 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_colsq_p, 3 * (size_t)n_pt));
-    TRY_RC(dalloc(h, &h->d_part_pt, 16 * (size_t)h->n_pt_blocks)); TRY_RC(dalloc(h, &h->d_part_back, 4 * (size_t)h->n_pt_blocks));
+    TRY_RC(dalloc(h, &h->d_part_pt, 32 * (size_t)h->n_pt_blocks)); TRY_RC(dalloc(h, &h->d_part_back, 4 * (size_t)h->n_pt_blocks));
     TRY_RC(dalloc(h, &h->d_part_cam, (size_t)CAMACC * n_cam * 32));
     TRY_RC(dalloc(h, &h->d_Linv, (size_t)(h->npad_max / NB) * NB * NB)); TRY_RC(dalloc(h, &h->d_y, (size_t)h->npad_max));
     TRY_RC(dalloc(h, &h->d_back4, 4)); TRY_RC(dalloc(h, &h->d_cam2, 2)); TRY_RC(dalloc(h, &h->d_xnorm, 64)); TRY_RC(dalloc(h, &h->d_err, 1));

@@ -41,7 +41,7 @@ struct BADev {
     // reduced system message: S (npad x npad) | rhs (npad) | diagU (npad) | graw (npad) | scal
     double* S; double* rhs; double* diagU; double* graw; double* scal;
     // partials
-    double* part_pt;    // [pt blocks][16]
+    double* part_pt;    // [pt blocks][32]
     double* part_cam;   // [nc][cam_split][80]
     double* part_back;  // [pt blocks][4]
     // solution of the reduced system (scaled coordinates, y; step = -y)
@@ -357,15 +357,16 @@ __device__ __forceinline__ double wave_reduce_scatter(const double (&a)[N], int 
 // K_pt: one thread per point.  V_p = sum F'F + D_p^2, b_p = sum F'r, WK_p = sum EK'F; stores V_p^-1, b_p, WK_p,
 // the raw squared column norms, and per-block partials of: cost, the point-eliminated intrinsic terms
 // SKK = sum WK V^-1 WK' (10), gK = sum WK V^-1 b (4), max |gradient| over the block's point columns.
-// part_pt[block][16] = { cost, SKK[10], gK[4], gmax }
+// part_pt[block][32] = { cost, SKK[10], gK[4], gmax, UKK = sum EK'EK [10], sum EK'r [4], - , - }: the last two sums run over
+// every observation, so they are taken here, where each observation is linearised with its intrinsic columns anyway
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict__ err)
 {
-    __shared__ double red[4][16];
+    __shared__ double red[4][32];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    double acc[16];
+    double acc[30];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    for (int i = 0; i < 30; ++i) acc[i] = 0.0;
     // per-point results, stored after the block below through a per-wave LDS transposition (see there)
     double Vi[6] = { 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 }, WK[12], cs[3] = { 0, 0, 0 };
 #pragma unroll
@@ -384,6 +385,15 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
             cost += 0.5 * o.rho0;
             // two chained fma per sum (x*y + z*w + acc would be mul, fma, add)
 #define ACC2(dst, x0, y0, x1, y1) do { dst = fma(x0, y0, dst); dst = fma(x1, y1, dst); } while (0)
+            if (!P.fixK) {
+                int a = 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) { ACC2(acc[a], o.EK[0][i], o.EK[0][j], o.EK[1][i], o.EK[1][j]); ++a; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ACC2(acc[26 + i], o.EK[0][i], o.r[0], o.EK[1][i], o.r[1]);
+            }
             ACC2(V[0], o.F[0][0], o.F[0][0], o.F[1][0], o.F[1][0]);
             ACC2(V[1], o.F[0][1], o.F[0][0], o.F[1][1], o.F[1][0]);
             ACC2(V[2], o.F[0][1], o.F[0][1], o.F[1][1], o.F[1][1]);
@@ -453,21 +463,21 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
         }
     }
     {
-        double v15[15];
+        double v29[29];                     // the 29 sums: slots 0..14 and 16..29 (slot 15 is a maximum)
 #pragma unroll
-        for (int i = 0; i < 15; ++i) v15[i] = acc[i];
-        const double tot = wave_reduce_scatter(v15, lane);
+        for (int i = 0; i < 29; ++i) v29[i] = acc[i < 15 ? i : i + 1];
+        const double tot = wave_reduce_scatter(v29, lane);
         const double gm = wave_max(acc[15]);
         const int j = wave_scatter_index(lane);
-        if (j < 15) red[wave][j] = tot;
+        if (j < 29) red[wave][j < 15 ? j : j + 1] = tot;
         if (lane == 0) red[wave][15] = gm;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 30) {
         const int i = threadIdx.x;
         double v = red[0][i];
         for (int w = 1; w < 4; ++w) v = (i == 15) ? fmax(v, red[w][i]) : v + red[w][i];
-        P.part_pt[16 * (size_t)blockIdx.x + i] = v;
+        P.part_pt[32 * (size_t)blockIdx.x + i] = v;
     }
 }
 
@@ -476,8 +486,7 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
 //   [0,21)  Scc  = Ec'Ec - T Wc'        (lower 6x6)          T = (Ec'F) V^-1
 //   [21,45) ScK  = Ec'EK - T WK_p'      (6x4)
 //   [45,51) rhs_c = Ec'r - T b_p
-//   [51,61) UKK  = EK'EK                (lower 4x4)
-//   [61,65) gK   = EK'r
+//   [51,65) unused (UKK = EK'EK and gK = EK'r are summed by K_pt)
 //   [65,71) diagU_c = diag(Ec'Ec)
 //   [71,77) graw_c = Ec'r
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(256) void ba_point_kernel(BADev P, int* __restrict_
 // 42 % waiting on its gathers with nothing else resident to issue (140 us; the split form: see profiles/README.md).
 __host__ __device__ constexpr int cam_part_slot(int part, int j)
 {
-    return part == 0 ? (j < 21 ? j : j < 27 ? 45 + (j - 21) : 65 + (j - 27)) : (j < 24 ? 21 + j : 51 + (j - 24));
+    return part == 0 ? (j < 21 ? j : j < 27 ? 45 + (j - 21) : 65 + (j - 27)) : 21 + j;
 }
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch) with its own 4 MB L2.  Work item v = (L % 8) * per + L / 8
 // gives every XCD one contiguous range of items: consecutive cameras (and camera pairs) share most of their points, so
@@ -573,18 +582,11 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[a] = fma(o.Ec[0][i], H0[j], acc[a]); acc[a] = fma(o.Ec[1][i], H1[j], acc[a]); ++a; }
-            a = 51;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) { acc[a] = fma(o.EK[0][i], o.EK[0][j], acc[a]); acc[a] = fma(o.EK[1][i], o.EK[1][j], acc[a]); ++a; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[61 + i] = fma(o.EK[0][i], o.r[0], acc[61 + i]); acc[61 + i] = fma(o.EK[1][i], o.r[1], acc[61 + i]); }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // this part's slots: part 0 -> [0,21) u [45,51) u [65,77), part 1 -> [21,45) u [51,65)
-    constexpr int NV = (PART == 0) ? 39 : 38;
+    // this part's slots: part 0 -> [0,21) u [45,51) u [65,77), part 1 -> [21,45)
+    constexpr int NV = (PART == 0) ? 39 : 24;
     double v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = acc[cam_part_slot(PART, j)];
@@ -594,7 +596,7 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     __syncthreads();
     if (threadIdx.x < 77) {
         const int i = threadIdx.x;
-        const bool mine = (PART == 0) ? (i < 21 || (i >= 45 && i < 51) || i >= 65) : ((i >= 21 && i < 45) || (i >= 51 && i < 65));
+        const bool mine = (PART == 0) ? (i < 21 || (i >= 45 && i < 51) || i >= 65) : (i >= 21 && i < 45);
         if (mine) P.part_cam[((size_t)c * P.cam_split + sp_i) * CAMACC + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     }
 }
@@ -646,33 +648,23 @@ __global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_bloc
         return;
     }
     // intrinsic block + scalars
-    double acc[16];
+    double acc[30];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    for (int i = 0; i < 30; ++i) acc[i] = 0.0;
     for (int b = tid; b < n_pt_blocks; b += 256) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) acc[i] += P.part_pt[16 * (size_t)b + i];
-        acc[15] = fmax(acc[15], P.part_pt[16 * (size_t)b + 15]);
-    }
-    double u[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) u[i] = 0.0;
-    for (int q = tid; q < P.nc * P.cam_split; q += 256) {
-#pragma unroll
-        for (int i = 0; i < 14; ++i) u[i] += P.part_cam[(size_t)q * CAMACC + 51 + i];
+        for (int i = 0; i < 30; ++i) {
+            const double v = P.part_pt[32 * (size_t)b + i];
+            acc[i] = (i == 15) ? fmax(acc[i], v) : acc[i] + v;
+        }
     }
     __shared__ double red[4][32];
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 15; ++i) acc[i] = wave_sum(acc[i]);
-    acc[15] = wave_max(acc[15]);
-#pragma unroll
-    for (int i = 0; i < 14; ++i) u[i] = wave_sum(u[i]);
+    for (int i = 0; i < 30; ++i) acc[i] = (i == 15) ? wave_max(acc[i]) : wave_sum(acc[i]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[wave][i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 14; ++i) red[wave][16 + i] = u[i];
+        for (int i = 0; i < 30; ++i) red[wave][i] = acc[i];
     }
     __syncthreads();
     if (tid < 30) {
