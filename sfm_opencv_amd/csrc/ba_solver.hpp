@@ -291,7 +291,17 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // 2. panel rows x L^-T = B (L^-1)' on the fp64 MFMA: one 16-row tile per wave at a time, both 16-column halves
         // (columns < 16 only see k < 16: L^-1 is lower triangular).  The tile's operand rows are in registers before
         // the results overwrite them; tiles of different waves touch disjoint rows.
-        const int nrows = R * SNB + 1;
+        // (the right-hand-side row is solved on the VALU by the last wave: as a ninth 16-row tile it cost panels with four row
+        //  blocks a second round of tiles)
+        const int nrows = R * SNB;
+        if (wave == SWAVES - 1 && !(pl.dbg & 2)) {
+            const int j = lane & 31;
+            double z4[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int m = 0; m < SNB; ++m) z4[m & 3] = fma(s.B[R * SNB][m], s.W[SNB + m][j], z4[m & 3]);
+            const double z = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+            if (lane < SNB) { s.B[R * SNB][j] = z; rhs[k * SNB + j] = z; }
+        }
         for (int rt = wave; rt * 16 < nrows && !(pl.dbg & 2); rt += SWAVES) {
             double a[8];
 #pragma unroll
@@ -306,7 +316,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 const int t = 16 * rt + lk + 4 * g;
                 if (t < nrows) {
                     s.B[t][li] = x0[g]; s.B[t][16 + li] = x1[g];
-                    double* gp = (t < R * SNB) ? A + (size_t)(Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB : rhs + k * SNB;
+                    double* gp = A + (size_t)(Rows[t >> 5] * SNB + (t & 31)) * ld + k * SNB;
                     gp[li] = x0[g]; gp[16 + li] = x1[g];
                 }
             }
