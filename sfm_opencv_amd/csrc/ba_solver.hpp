@@ -65,7 +65,8 @@ struct DiagLds {
 struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
-    int Rows2[2][SRMAX];                // block rows of the current / next panel (double-buffered by panel parity)
+    int Rows3[3][SRMAX];                // block rows of panels k, k + 1, k + 2 (slot = panel % 3): the idle wave fetches two panels
+                                        // ahead, so no panel waits for its row list
     // trailing-update block pairs of the current panel: { first row of the A operand in B, first row of the B operand,
     // address of the 32x32 target block (lo, hi) } and the target's leading dimension; double-buffered by panel parity
     // (the idle wave fills the next panel's table while the others walk the current one)
@@ -216,10 +217,10 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     const int li = lane & 15, lk = lane >> 4;
 #define STAMP(i) do { if (pl.stamps && tid == 0) pl.stamps[(size_t)k * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     if (k0 >= k1) return true;
-    // block-pair table of panel kk (rows in s.Rows2[kk & 1]): pairs (qi >= qj) in row-major order of the lower triangle
+    // block-pair table of panel kk (rows in s.Rows3[kk % 3]): pairs (qi >= qj) in row-major order of the lower triangle
     auto fill_pairs = [&](int kk, int first, int step) {
         const int Rk = pl.prow_start[kk + 1] - pl.prow_start[kk], np = Rk * (Rk + 1) / 2;
-        const int* Rw = s.Rows2[kk & 1];
+        const int* Rw = s.Rows3[kk % 3];
         for (int pr = first; pr < np; pr += step) {
             int qi = 0, qj = pr; while (qj > qi) { qj -= qi + 1; ++qi; }
             const int bi = Rw[qi], bjb = Rw[qj];
@@ -232,20 +233,21 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         }
     };
     // prologue: first pivot block, and the first panel's block-row list
-    { const int q0 = pl.prow_start[k0], Rq = pl.prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows2[k0 & 1][tid] = pl.prow[q0 + tid]; }
+    { const int q0 = pl.prow_start[k0], Rq = pl.prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows3[k0 % 3][tid] = pl.prow[q0 + tid]; }
+    if (k0 + 1 < k1) { const int q1 = pl.prow_start[k0 + 1], Rq = pl.prow_start[k0 + 2] - q1; if (tid >= 64 && tid - 64 < Rq) s.Rows3[(k0 + 1) % 3][tid - 64] = pl.prow[q1 + tid - 64]; }
     for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k0 * SNB + r) * ld + k0 * SNB + c];
     __syncthreads();
     if (wave == 0 && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
     else if (wave > 0) fill_pairs(k0, tid - 64, STHREADS - 64);
     __syncthreads();
+    double rhs_next = 0.0; bool rhs_in_reg = false;      // wave 4, lanes 0..31: the next panel's right-hand-side block, carried in a register
     for (int k = k0; k < k1; ++k) {
         const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
         const int npairs = R * (R + 1) / 2;
         const bool has_next = k + 1 < k1;
-        const bool next_diag = has_next && R > 0 && pl.prow[p0] == k + 1;         // this panel updates the next pivot block (uniform scalar load)
         STAMP(0);
-        int* Rows = s.Rows2[k & 1];       // written one panel ago (before the full barrier): no dependent index load in front of the staging
-        if (has_next) { const int q0 = pl.prow_start[k + 1], Rq = pl.prow_start[k + 2] - q0; if (tid < Rq) s.Rows2[(k + 1) & 1][tid] = pl.prow[q0 + tid]; }
+        int* Rows = s.Rows3[k % 3];       // fetched two panels ago: no index load in front of the staging
+        const bool next_diag = has_next && R > 0 && __builtin_amdgcn_readfirstlane(Rows[0]) == k + 1;     // this panel updates the next pivot block
         // requests whose latency hides behind the staging and the panel solve: this wave's tile of the next pivot block
         // and the right-hand-side entries waves 1..3 update in step 4
         v4d old0 = { 0.0, 0.0, 0.0, 0.0 };
@@ -280,7 +282,9 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                     if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; s.B[q * SNB + rr][cc] = tmp[i]; }
                 }
             }
-            if (wave == 3 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
+            // this panel's right-hand-side block: the previous panel's wave 4 still holds it when it was the one to update it
+            if (rhs_in_reg) { if (wave == 4 && lane < 32) s.B[R * SNB][lane] = rhs_next; }
+            else if (wave == 3 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
             for (int r = r0; r < SNB; r += SROWS) {
                 A[(size_t)(k * SNB + r) * ld + k * SNB + c] = s.D[r][c];
                 pl.linv[(size_t)k * SNB * SNB + r * SNB + c] = s.W[SNB + r][c];
@@ -404,10 +408,14 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                     const int bi = Rows[t >> 5];
                     if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] = rhs_old[u] - v;
                     else rhs[bi * SNB + (t & 31)] = rhs_old[u] - v;
+                    if (u == 0 && t < SNB) rhs_next = rhs_old[u] - v;       // rows 0..31 are block Rows[0] (= k + 1 if next_diag)
                 }
             }
+            // the row list of panel k + 2 (slot (k + 2) % 3 is free: panel k - 1 is done)
+            if (wave == 4 && k + 2 < k1) { const int q2 = pl.prow_start[k + 2], R2 = pl.prow_start[k + 3] - q2; if (lane < R2) s.Rows3[(k + 2) % 3][lane] = pl.prow[q2 + lane]; }
             if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 3] = (long long)__builtin_amdgcn_s_memtime();
         }
+        rhs_in_reg = next_diag && !(pl.dbg & 4);
         __syncthreads();                    // full: the next panel stages from what this one wrote to global
         STAMP(6);
     }
