@@ -269,6 +269,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // 1. stage the row blocks (batches of 8 loads in flight per thread) and the rhs row; L_kk to global
         {
             const int total = R * SNB * SNB;
+            for (int rep = 0; rep < ((pl.dbg & 128) ? 2 : 1); ++rep)         // (dbg 128: stage twice, a timing experiment)
             for (int e0 = tid; e0 < total && !(pl.dbg & 8); e0 += SSTAGE * STHREADS) {      // <= 4 row blocks: one round trip
                 double tmp[SSTAGE];
 #pragma unroll
