@@ -211,6 +211,12 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tid >> 5, c = tid & 31;
     const int ntop = (pl.nb - pl.top_blk) * SNB;
+    // The plan arrays are read-only for the kernel: through a constant-address-space pointer their loads are scalar (s_load).
+    // As plain global loads (the kernel also stores, so the compiler must assume aliasing) the two prow_start reads at the
+    // top of every panel came with an s_waitcnt vmcnt(0) -- a wait for every outstanding store and atomic of the wave,
+    // ~2k cycles per panel.
+    typedef const int __attribute__((address_space(4)))* cint_p;
+    const cint_p prow_start = (cint_p)pl.prow_start;
     bool ok = true;
     constexpr int NT = SWAVES - 2;       // waves that share the trailing update: all but wave 0 (pivot chain) and wave 4, which
                                          // shares wave 0's SIMD (the chain runs 8 % slower with a busy neighbour)
@@ -219,7 +225,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     if (k0 >= k1) return true;
     // block-pair table of panel kk (rows in s.Rows3[kk % 3]): pairs (qi >= qj) in row-major order of the lower triangle
     auto fill_pairs = [&](int kk, int first, int step) {
-        const int Rk = pl.prow_start[kk + 1] - pl.prow_start[kk], np = Rk * (Rk + 1) / 2;
+        const int Rk = prow_start[kk + 1] - prow_start[kk], np = Rk * (Rk + 1) / 2;
         const int* Rw = s.Rows3[kk % 3];
         for (int pr = first; pr < np; pr += step) {
             int qi = 0, qj = pr; while (qj > qi) { qj -= qi + 1; ++qi; }
@@ -233,8 +239,8 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         }
     };
     // prologue: first pivot block, and the first panel's block-row list
-    { const int q0 = pl.prow_start[k0], Rq = pl.prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows3[k0 % 3][tid] = pl.prow[q0 + tid]; }
-    if (k0 + 1 < k1) { const int q1 = pl.prow_start[k0 + 1], Rq = pl.prow_start[k0 + 2] - q1; if (tid >= 64 && tid - 64 < Rq) s.Rows3[(k0 + 1) % 3][tid - 64] = pl.prow[q1 + tid - 64]; }
+    { const int q0 = prow_start[k0], Rq = prow_start[k0 + 1] - q0; if (tid < Rq) s.Rows3[k0 % 3][tid] = pl.prow[q0 + tid]; }
+    if (k0 + 1 < k1) { const int q1 = prow_start[k0 + 1], Rq = prow_start[k0 + 2] - q1; if (tid >= 64 && tid - 64 < Rq) s.Rows3[(k0 + 1) % 3][tid - 64] = pl.prow[q1 + tid - 64]; }
     for (int r = r0; r < SNB; r += SROWS) s.D[r][c] = A[(size_t)(k0 * SNB + r) * ld + k0 * SNB + c];
     __syncthreads();
     if (wave == 0 && !(pl.dbg & 1)) ok = wave_chol32(s, lane) && ok;
@@ -242,7 +248,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     __syncthreads();
     double rhs_next = 0.0; bool rhs_in_reg = false;      // wave 4, lanes 0..31: the next panel's right-hand-side block, carried in a register
     for (int k = k0; k < k1; ++k) {
-        const int p0 = pl.prow_start[k], R = pl.prow_start[k + 1] - p0;
+        const int p0 = prow_start[k], R = prow_start[k + 1] - p0;
         const int npairs = R * (R + 1) / 2;
         const bool has_next = k + 1 < k1;
         STAMP(0);
@@ -266,23 +272,24 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 rhs_old[u] = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (t & 31)] : rhs[bi * SNB + (t & 31)];
             }
         }
-        // 1. stage the row blocks (batches of 8 loads in flight per thread) and the rhs row; L_kk to global
+        // 1. No staging pass: every wave requests the 16 rows of its own solve tile straight into the MFMA operand layout
+        //    (a lane's eight values sit 32 B apart in one row), so the unsolved rows never go through LDS and the request is in
+        //    flight across the write-back and the barrier below (staging was a 1.6k-cycle L2 round trip plus an LDS write,
+        //    a barrier and an LDS read in front of the first MFMA).  The rhs row goes to LDS; L_kk and its inverse to global.
+        const int nrows = R * SNB;
+        auto tile_src = [&](int rt) -> const double* {
+            const int row = 16 * rt + li;
+            return A + (size_t)(Rows[row >> 5] * SNB + (row & 31)) * ld + k * SNB + lk;
+        };
+        double a_pre[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a_pre[kk] = 0.0;
+        if (wave * 16 < nrows && !(pl.dbg & 8)) {
+            const double* src = tile_src(wave);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a_pre[kk] = src[4 * kk];
+        }
         {
-            const int total = R * SNB * SNB;
-            for (int rep = 0; rep < ((pl.dbg & 128) ? 2 : 1); ++rep)         // (dbg 128: stage twice, a timing experiment)
-            for (int e0 = tid; e0 < total && !(pl.dbg & 8); e0 += SSTAGE * STHREADS) {      // <= 4 row blocks: one round trip
-                double tmp[SSTAGE];
-#pragma unroll
-                for (int i = 0; i < SSTAGE; ++i) {
-                    const int e = e0 + i * STHREADS;
-                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; tmp[i] = A[(size_t)(Rows[q] * SNB + rr) * ld + k * SNB + cc]; }
-                }
-#pragma unroll
-                for (int i = 0; i < SSTAGE; ++i) {
-                    const int e = e0 + i * STHREADS;
-                    if (e < total) { const int q = e >> 10, rr = (e >> 5) & 31, cc = e & 31; s.B[q * SNB + rr][cc] = tmp[i]; }
-                }
-            }
             // this panel's right-hand-side block: the previous panel's wave 4 still holds it when it was the one to update it
             if (rhs_in_reg) { if (wave == 4 && lane < 32) s.B[R * SNB][lane] = rhs_next; }
             else if (wave == 3 && lane < 32) s.B[R * SNB][lane] = rhs[k * SNB + lane];
@@ -298,7 +305,6 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         // the results overwrite them; tiles of different waves touch disjoint rows.
         // (the right-hand-side row is solved on the VALU by the last wave: as a ninth 16-row tile it cost panels with four row
         //  blocks a second round of tiles)
-        const int nrows = R * SNB;
         if (wave == SWAVES - 1 && !(pl.dbg & 2)) {
             const int j = lane & 31;
             double z4[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -309,8 +315,14 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
         }
         for (int rt = wave; rt * 16 < nrows && !(pl.dbg & 2); rt += SWAVES) {
             double a[8];
+            if (rt == wave) {
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a[kk] = s.B[16 * rt + li][4 * kk + lk];        // rows past nrows: stale LDS, results dropped
+                for (int kk = 0; kk < 8; ++kk) a[kk] = a_pre[kk];
+            } else {                        // more than SWAVES tiles (five or more row blocks): later tiles are requested here
+                const double* src = tile_src(rt);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) a[kk] = src[4 * kk];
+            }
             v4d x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], s.W[SNB + 4 * kk + lk][li], x0, 0, 0, 0);
@@ -413,7 +425,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                 }
             }
             // the row list of panel k + 2 (slot (k + 2) % 3 is free: panel k - 1 is done)
-            if (wave == 4 && k + 2 < k1) { const int q2 = pl.prow_start[k + 2], R2 = pl.prow_start[k + 3] - q2; if (lane < R2) s.Rows3[(k + 2) % 3][lane] = pl.prow[q2 + lane]; }
+            if (wave == 4 && k + 2 < k1) { const int q2 = prow_start[k + 2], R2 = prow_start[k + 3] - q2; if (lane < R2) s.Rows3[(k + 2) % 3][lane] = pl.prow[q2 + lane]; }
             if (pl.stamps && tid == 64) pl.stamps[(size_t)k * 16 + 3] = (long long)__builtin_amdgcn_s_memtime();
         }
         rhs_in_reg = next_diag && !(pl.dbg & 4);
@@ -435,15 +447,17 @@ __device__ __forceinline__ void backward_panels(SolverLds& s, const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tid >> 5, c = tid & 31;          // this thread's elements: rows r0 and r0 + 16 of column c
     if (k_hi <= k_lo) return;
+    typedef const int __attribute__((address_space(4)))* cint_p;
+    const cint_p prow_start = (cint_p)pl.prow_start; const cint_p prow = (cint_p)pl.prow;
     struct PanelRegs { double lb[SRMAX][2]; double wt[2]; int rows[SRMAX]; int R; };
     auto load_panel = [&](PanelRegs& P, int k) {
-        const int p0 = pl.prow_start[k];
-        P.R = pl.prow_start[k + 1] - p0;
+        const int p0 = prow_start[k];
+        P.R = prow_start[k + 1] - p0;
 #pragma unroll
         for (int q = 0; q < SRMAX; ++q) {
             P.rows[q] = 0; P.lb[q][0] = 0.0; P.lb[q][1] = 0.0;
             if (q < P.R) {
-                const int i = pl.prow[p0 + q];
+                const int i = prow[p0 + q];
                 P.rows[q] = i;
                 P.lb[q][0] = A[(size_t)(i * SNB + r0) * ld + k * SNB + c];
                 P.lb[q][1] = A[(size_t)(i * SNB + r0 + 16) * ld + k * SNB + c];
