@@ -208,7 +208,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     //      of panel k's trailing update and its right-hand-side update                                    | full barrier
     // so the factorisation (12.7k cycles) no longer adds to the trailing update, the rhs update and the prefetches
     // (11k cycles together): measured per panel 29.6k -> see profiles/README.md.
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: role tests become scalar branches
     const int r0 = tid >> 5, c = tid & 31;
     const int ntop = (pl.nb - pl.top_blk) * SNB;
     // The plan arrays are read-only for the kernel: through a constant-address-space pointer their loads are scalar (s_load).
@@ -444,7 +444,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
 __device__ __forceinline__ void backward_panels(SolverLds& s, const double* __restrict__ A, int ld, int k_lo, int k_hi,
                                                 const SolverPlan pl, double* sy)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: role tests become scalar branches
     const int r0 = tid >> 5, c = tid & 31;          // this thread's elements: rows r0 and r0 + 16 of column c
     if (k_hi <= k_lo) return;
     typedef const int __attribute__((address_space(4)))* cint_p;
