@@ -138,6 +138,11 @@ int sfmhip_match_pairs(sfmhip_ctx*, sfmhip_descset* const* sets, int n_sets,
 int sfmhip_l2_distance_matrix_dev(sfmhip_ctx*, const sfmhip_descset* query, const sfmhip_descset* train,
                                   float* d_dist, size_t ld, int force_path);
 
+/* Self-test of the distance epilogue: the materialised matrix takes sqrtf of exact integers < 2^24 with a short
+ * correctly-rounded sequence (v_sqrt_f32 + neighbour test); this runs it over every such integer on the device and
+ * returns in *mismatches how many results differ from sqrtf (must be 0).  Synchronises. */
+int sfmhip_selftest_exact_sqrt(sfmhip_ctx*, int* mismatches);
+
 /* ------------------------------------------------------------------------------------------ */
 /* triangulation: replaces cv::triangulatePoints + the float32 de-homogenisation loop of       */
 /* reconstruct (NView:1147-1156).  P1,P2: row-major 3x4 float32 (= float(K)*[float(R)|float(T)],*/

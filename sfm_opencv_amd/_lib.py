@@ -48,7 +48,7 @@ SYMBOLS = [
     "sfmhip_descset_destroy", "sfmhip_descset_refresh", "sfmhip_descsets_refresh", "sfmhip_descset_info",
     "sfmhip_knn2_dev", "sfmhip_knn2_l2_f32", "sfmhip_knn2_hamming2_u8", "sfmhip_ratio_filter",
     "sfmhip_match_features_l2", "sfmhip_match_features_hamming2",
-    "sfmhip_match_pairs_dev", "sfmhip_match_pairs", "sfmhip_l2_distance_matrix_dev",
+    "sfmhip_match_pairs_dev", "sfmhip_match_pairs", "sfmhip_l2_distance_matrix_dev", "sfmhip_selftest_exact_sqrt",
     "sfmhip_triangulate2_f32", "sfmhip_triangulate2_f32_dev", "sfmhip_triangulate2_matches_dev",
     "sfmhip_triangulate_tracks", "sfmhip_reprojection_errors",
     "sfmhip_ba_default_options", "sfmhip_ba_solve", "sfmhip_ba_create", "sfmhip_ba_destroy",
@@ -102,6 +102,7 @@ def load():
         "sfmhip_match_pairs_dev": (i32, [vp, C.POINTER(vp), i32, vp, i32, f64, f32, f32, vp, i32, vp]),
         "sfmhip_match_pairs": (i32, [vp, C.POINTER(vp), i32, vp, i32, f64, f32, f32, vp, i32, vp]),
         "sfmhip_l2_distance_matrix_dev": (i32, [vp, vp, vp, vp, sz, i32]),
+        "sfmhip_selftest_exact_sqrt": (i32, [vp, C.POINTER(i32)]),
         "sfmhip_triangulate2_f32": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
         "sfmhip_triangulate2_f32_dev": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
         "sfmhip_triangulate2_matches_dev": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),

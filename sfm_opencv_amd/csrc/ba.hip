@@ -210,6 +210,8 @@ struct sfmhip_ba {
     bool publish_in_back = false, published = false;   // ba_loop asks enqueue_back to publish the step scalars from its reduction kernel
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
+    bool force_dense = false;      // SFMHIP_EXPERIMENTS builds: SFMHIP_DENSE_SOLVER routes every problem to the dense fallback
+    long long* d_stamps = nullptr; int stamp_calls = 0;      // SFMHIP_EXPERIMENTS builds only: per-panel cycle stamps of the solver
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
@@ -250,7 +252,9 @@ static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = fal
     P.part_pt = h->d_part_pt; P.part_cam = h->d_part_cam; P.part_back = h->d_part_back;
     P.y = h->d_y;
     P.radius = radius; P.min_diag = h->o.min_lm_diagonal; P.max_diag = h->o.max_lm_diagonal;
-    { static const int plain = getenv("SFMHIP_EXP_XCD_PLAIN") ? 1 : 0; P.xcd_plain = plain; }
+#ifdef SFMHIP_EXPERIMENTS
+    { static const int plain = getenv("SFMHIP_EXP_XCD_PLAIN") ? 1 : 0; P.xcd_plain = plain; }      // measurement knob (profiles/r01_traffic_pmc.md)
+#endif
     if (at_candidate) {
         P.K = h->d_Kc; P.ext = h->d_extc; P.pts = h->d_ptsc; P.Kc = h->d_K; P.extc = h->d_ext; P.ptsc = h->d_pts;
         P.campre = h->d_campre_c; P.campre_c = h->d_campre;
@@ -355,16 +359,19 @@ static int enqueue_solve(sfmhip_ba* h)
             pl.damp_diagU = P.diagU; pl.damp_mask = P.posmask; pl.damp_radius = h->damp_radius; pl.damp_min = P.min_diag; pl.damp_max = P.max_diag;
             h->solver_damps = false;
         }
-        { const char* e = getenv("SFMHIP_EXP_SOLVER"); pl.dbg = e ? atoi(e) : 0; }
-        static long long* d_stamps = nullptr; static int stamp_calls = 0;
-        pl.stamps = nullptr;
-        if (getenv("SFMHIP_SOLVER_STAMPS")) {
-            if (!d_stamps) { (void)hipMalloc((void**)&d_stamps, 16 * 512 * sizeof(long long)); (void)hipMemset(d_stamps, 0, 16 * 512 * sizeof(long long)); }
-            pl.stamps = d_stamps;
-            if (++stamp_calls == 8) {          // dump once, after a few warm iterations
+        pl.dbg = 0; pl.stamps = nullptr;
+#ifdef SFMHIP_EXPERIMENTS
+        // timing experiments (results are garbage with dbg != 0) and per-panel cycle stamps; read once per process
+        static const int exp_dbg = [] { const char* e = getenv("SFMHIP_EXP_SOLVER"); return e ? atoi(e) : 0; }();
+        static const bool exp_stamps = getenv("SFMHIP_SOLVER_STAMPS") != nullptr;
+        pl.dbg = exp_dbg;
+        if (exp_stamps) {
+            if (!h->d_stamps) { int rc = dalloc(h, &h->d_stamps, 16 * 512); if (rc) return rc; (void)hipMemset(h->d_stamps, 0, 16 * 512 * sizeof(long long)); }
+            pl.stamps = h->d_stamps;
+            if (++h->stamp_calls == 8) {          // dump once, after a few warm iterations
                 (void)hipStreamSynchronize(st);
                 std::vector<long long> hs(16 * (size_t)nb);
-                (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hs.data(), h->d_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 for (int k = 0; k < nb; ++k) {
                     fprintf(stderr, "[stamps] panel %3d: stage %6lld | solve %6lld | next pivot %6lld | factor (wave 0) %6lld | trailing tiles %6lld + rhs %6lld (wave 1) | join %6lld   cycles\n", k,
                             hs[16 * k + 1] - hs[16 * k + 0], hs[16 * k + 4] - hs[16 * k + 1], hs[16 * k + 5] - hs[16 * k + 4],
@@ -373,6 +380,7 @@ static int enqueue_solve(sfmhip_ba* h)
                 }
             }
         }
+#endif
         if (h->nseg <= 1) {
             pl.top_blk = nb;
             hipLaunchKernelGGL(chol_sparse_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, rhs_rw, h->d_y, h->d_err);
@@ -416,7 +424,9 @@ static int enqueue_back(sfmhip_ba* h, double radius)
                        d_scal, h->d_cam2, h->d_err, fuse_publish ? h->h_scal : (double*)nullptr, fuse_publish ? ++h->pub_seq : 0ull);
     h->published = fuse_publish;
     SFM_HIP_TRY(ctx, hipGetLastError());
-    return call_allreduce(h, h->d_back4, 4);
+    // five doubles: the four step scalars and this rank's error flag (a non-SPD V of a local point): every rank must take
+    // the same accept / invalid branch, or the replicated cameras, radius and nu diverge and the next all-reduce hangs
+    return call_allreduce(h, h->d_back4, 5);
 }
 
 // Layout + block fill pattern of the reduced system -> per-panel row lists for the solver kernels.
@@ -446,7 +456,10 @@ static int build_solver_plan(sfmhip_ba* h)
     for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c) if (adj[(size_t)a * ncf + c] != 0.0) w = std::max(w, a - c);
 
     int want = 4;
-    if (const char* e = getenv("SFMHIP_ND_SEGMENTS")) want = std::max(1, atoi(e));
+#ifdef SFMHIP_EXPERIMENTS
+    if (const char* e = getenv("SFMHIP_ND_SEGMENTS")) want = std::min(SRMAX, std::max(1, atoi(e)));     // chol_nd_top_kernel folds at most SRMAX private buffers
+#endif
+    static_assert(SRMAX + 1 <= 16, "d_seg_blk holds 16 entries");
     for (int attempt = 0; attempt < 2; ++attempt) {
         // ---- 2. ordering
         int P = attempt == 0 ? want : 1;
@@ -517,7 +530,7 @@ static int build_solver_plan(sfmhip_ba* h)
         h->max_panel_rows = maxR;
         h->nnz_blocks = (long long)rows.size() + nb;
         h->use_sparse = maxR <= SRMAX && npad <= (SRMAX * SNB + 1) * SLD;
-        if (getenv("SFMHIP_DENSE_SOLVER")) h->use_sparse = false;
+        if (h->force_dense) h->use_sparse = false;
         // ---- upload
         std::vector<int> mask((size_t)h->npad_max, 0);
         for (int i = 0; i < npad; ++i) mask[i] = h->pos_param[i] >= 0;
@@ -627,7 +640,11 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
     // good step), so that an accepted step finds its build already running.  Measured at C4: 11 of 12 guesses hit, results
     // bit-identical, but no gain (0.695 vs 0.686 ms per step): the round trip is ~10 us of a 0.67 ms iteration and the extra
     // enqueue work costs as much.  Off by default.
+#ifdef SFMHIP_EXPERIMENTS
     static const bool speculate = getenv("SFMHIP_SPECULATE") != nullptr;
+#else
+    constexpr bool speculate = false;
+#endif
     for (;;) {
         if (h->iter >= it_end) { h->termination = SFMHIP_BA_NO_CONVERGENCE; break; }
         if (!forced && h->radius < o.min_trust_region_radius) { h->termination = SFMHIP_BA_CONVERGENCE; break; }
@@ -750,6 +767,7 @@ void sfmhip_ba_default_options(sfm_ba_options* o)
 
 void sfmhip_ba_destroy(sfmhip_ba* h)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return;
     (void)hipStreamSynchronize(h->ctx->stream);
     for (void* p : h->allocs) (void)hipFree(p);
@@ -768,6 +786,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
                      const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
                      const sfm_ba_options* opts, sfmhip_ba** out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0);
     SFM_ARG_CHECK(ctx, (pts || n_pt == 0) && ((obs_cam && obs_pt && obs_uv) || n_obs == 0));
     for (int k = 0; k < n_obs; ++k)
@@ -781,6 +800,9 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->npad = std::max(NB, round_up(h->n, NB)); h->nbk = h->npad / NB;
     h->npad_max = h->npad + NB * 8;                 // room for the per-segment padding of the nested-dissection layout
     h->n_pt_blocks = std::max(1, ceil_div(n_pt, 256));
+#ifdef SFMHIP_EXPERIMENTS
+    h->force_dense = getenv("SFMHIP_DENSE_SOLVER") != nullptr;
+#endif
 
     // ---- orderings (host, once per problem)
     // Points are stored sorted by the set of cameras that see them (lexicographic on the ascending camera list):
@@ -820,7 +842,9 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     int max_cam = 1;
     for (int c = 0; c < n_cam; ++c) max_cam = std::max(max_cam, cam_start[c + 1] - cam_start[c]);
     int cam_wg_obs = 2048;            // observations per camera workgroup (8 per thread: the 39-value reduction is paid once per wave)
+#ifdef SFMHIP_EXPERIMENTS
     if (const char* e = getenv("SFMHIP_CAM_WG_OBS")) cam_wg_obs = std::max(256, atoi(e));
+#endif
     h->cam_split = std::min(32, std::max(1, ceil_div(max_cam, cam_wg_obs)));
     // camera-pair lists for the off-diagonal Schur blocks (and same-camera pairs)
     struct Item { long long key; int qi, qj; };
@@ -835,7 +859,9 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
             }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
     int schur_chunk = 512;            // pairs per wave: 8 trips of the 64-lane loop, then one cross-lane reduction
+#ifdef SFMHIP_EXPERIMENTS
     if (const char* e = getenv("SFMHIP_SCHUR_CHUNK")) schur_chunk = std::max(64, atoi(e));
+#endif
     std::vector<int> blk_cam, blk_chunk;
     std::vector<int4> flat(items.size()), chunk_desc;
     for (size_t t = 0; t < items.size();) {
@@ -886,7 +912,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dalloc(h, &h->d_part_pt, 32 * (size_t)h->n_pt_blocks)); TRY_RC(dalloc(h, &h->d_part_back, 4 * (size_t)h->n_pt_blocks));
     TRY_RC(dalloc(h, &h->d_part_cam, (size_t)CAMACC * n_cam * 32));
     TRY_RC(dalloc(h, &h->d_Linv, (size_t)(h->npad_max / NB) * NB * NB)); TRY_RC(dalloc(h, &h->d_y, (size_t)h->npad_max));
-    TRY_RC(dalloc(h, &h->d_back4, 4)); TRY_RC(dalloc(h, &h->d_cam2, 2)); TRY_RC(dalloc(h, &h->d_xnorm, 64)); TRY_RC(dalloc(h, &h->d_err, 1));
+    TRY_RC(dalloc(h, &h->d_back4, 8)); TRY_RC(dalloc(h, &h->d_cam2, 2)); TRY_RC(dalloc(h, &h->d_xnorm, 64)); TRY_RC(dalloc(h, &h->d_err, 1));
     h->msg_count = (size_t)h->npad_max * h->npad_max + 3 * (size_t)h->npad_max + SCAL_GMAX_SLOTS + 64;   // room for <= 64 ranks
     TRY_RC(dalloc(h, &h->d_msg, std::max(h->msg_count, (size_t)h->ncf * h->ncf)));
 #undef TRY_RC
@@ -905,6 +931,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
 
 int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, int rank, int world)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h || world < 1 || world > 64 || rank < 0 || rank >= world) return SFMHIP_E_ARG;
     h->ar_fn = fn; h->ar_user = user; h->rank = rank; h->world = world;
     h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
@@ -913,6 +940,7 @@ int sfmhip_ba_set_allreduce(sfmhip_ba* h, sfmhip_allreduce_fn fn, void* user, in
 
 int sfmhip_ba_reset(sfmhip_ba* h)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return SFMHIP_E_ARG;
     sfmhip_ctx* ctx = h->ctx;
     SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_K, h->d_K0, 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -925,6 +953,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
 
 int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
@@ -935,6 +964,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 
 int sfmhip_ba_iterate(sfmhip_ba* h, int n_iter, sfm_ba_summary* summary)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h || n_iter < 0) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
@@ -945,6 +975,7 @@ int sfmhip_ba_iterate(sfmhip_ba* h, int n_iter, sfm_ba_summary* summary)
 
 int sfmhip_ba_get_params(sfmhip_ba* h, double* K4, double* ext6, double* pts)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return SFMHIP_E_ARG;
     sfmhip_ctx* ctx = h->ctx;
     SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -961,6 +992,7 @@ int sfmhip_ba_get_params(sfmhip_ba* h, double* K4, double* ext6, double* pts)
 
 int sfmhip_ba_reduced_system(sfmhip_ba* h, double radius, double* S, double* rhs, int* n, double* cost)
 {
+    SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return SFMHIP_E_ARG;
     sfmhip_ctx* ctx = h->ctx;
     if (n) *n = h->n;
@@ -997,6 +1029,7 @@ int sfmhip_ba_solve(sfmhip_ctx* ctx, double* K4, double* ext6, int n_cam, double
                     const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
                     const sfm_ba_options* opts, sfm_ba_summary* summary)
 {
+    SFM_DEVICE_GUARD(ctx);
     sfmhip_ba* h = nullptr;
     int rc = sfmhip_ba_create(ctx, K4, ext6, n_cam, pts, n_pt, obs_cam, obs_pt, obs_uv, n_obs, opts, &h);
     if (rc) return rc;

@@ -894,7 +894,11 @@ __global__ void ba_publish_kernel(const double* __restrict__ scal2, const double
     if (l < 2) host_out[l] = scal2[l];
     else if (l < 6) host_out[l] = back4[l - 2];
     else if (l < 8) host_out[l] = cam2[l - 6];
-    else if (l == 8) { host_out[8] = (double)*err; if (clear_err) *err = 0; }
+    else if (l == 8) {
+        // clear_err == 0 <=> multi-rank: back4[4] is the all-reduced flag count, the local flag is re-armed by the next build
+        host_out[8] = clear_err ? (double)*err : ((*err != 0 || back4[4] > 0.0) ? 1.0 : 0.0);
+        if (clear_err) *err = 0;
+    }
     __threadfence_system();
     __syncthreads();
     if (l == 0) __hip_atomic_store((unsigned long long*)(host_out + 15), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1041,6 +1045,8 @@ __global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __res
         out4[threadIdx.x] = v;
         if (host_out) host_out[2 + threadIdx.x] = v;
     }
+    // multi-rank: the error flag travels with the step scalars (summed by the all-reduce: > 0 on every rank if any rank set it)
+    if (!host_out && threadIdx.x == 4) out4[4] = *err != 0 ? 1.0 : 0.0;
     if (host_out) {
         const int l = threadIdx.x;
         if (l >= 64 && l < 66) host_out[l - 64] = scal2[l - 64];

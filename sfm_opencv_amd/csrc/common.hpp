@@ -28,6 +28,21 @@ struct sfmhip_ctx {
     hipEvent_t tev[TIMING_SLOTS][3] = {};
 };
 
+// Every C-ABI entry point binds the calling thread to its context's device for the duration of the call (and restores the
+// caller's current device): allocations, event creation and launches then land on ctx->device whatever the caller did
+// with hipSetDevice in between, and two contexts on different GPUs can live in one process.
+struct SfmDeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit SfmDeviceGuard(const sfmhip_ctx* c)
+    {
+        if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~SfmDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    SfmDeviceGuard(const SfmDeviceGuard&) = delete;
+    SfmDeviceGuard& operator=(const SfmDeviceGuard&) = delete;
+};
+#define SFM_DEVICE_GUARD(ctx) SfmDeviceGuard _sfm_device_guard(ctx)
+
 #define SFM_HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

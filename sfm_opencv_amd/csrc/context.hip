@@ -26,6 +26,7 @@ int sfmhip_create(int device, sfmhip_ctx** out)
 
 void sfmhip_destroy(sfmhip_ctx* ctx)
 {
+    SFM_DEVICE_GUARD(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -38,6 +39,7 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
 
 int sfmhip_set_kernel_timing(sfmhip_ctx* ctx, int enable)
 {
+    SFM_DEVICE_GUARD(ctx);
     if (!ctx) return SFMHIP_E_ARG;
     if (enable) {
         for (auto& t : ctx->tev) for (auto& e : t) if (!e) SFM_HIP_TRY(ctx, hipEventCreate(&e));
@@ -49,6 +51,7 @@ int sfmhip_set_kernel_timing(sfmhip_ctx* ctx, int enable)
 
 int sfmhip_match_kernel_ms(sfmhip_ctx* ctx, double out_ms[4])
 {
+    SFM_DEVICE_GUARD(ctx);
     if (!ctx || !out_ms) return SFMHIP_E_ARG;
     out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.0;
     SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -74,6 +77,7 @@ int sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream)
 
 int sfmhip_synchronize(sfmhip_ctx* ctx)
 {
+    SFM_DEVICE_GUARD(ctx);
     if (!ctx) return SFMHIP_E_ARG;
     SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SFMHIP_OK;

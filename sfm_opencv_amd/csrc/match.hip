@@ -277,8 +277,9 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
 
-#ifndef KNN_EXP
-#define KNN_EXP 0              // timing experiments only (wrong results): 1 = no staging / barriers after the first block
+#if !defined(KNN_EXP) || !defined(SFMHIP_EXPERIMENTS)
+#undef KNN_EXP
+#define KNN_EXP 0              // timing experiments only (SFMHIP_EXPERIMENTS builds; wrong results): 1 = no staging / barriers after the first block
 #endif
     if (nblocks > 0) g_stage(B0{}, 0);
     __syncthreads();
@@ -364,8 +365,14 @@ template <int KS>
 __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
                                                          const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
                                                          int nq, int nt, int nt_pad, int blocks_per_wg,
-                                                         float* __restrict__ dist, size_t ldd, int vec_ok, int exp_mode)
+                                                         float* __restrict__ dist, size_t ldd, int vec_ok, int exp_mode_arg)
 {
+#ifdef SFMHIP_EXPERIMENTS
+    const int exp_mode = exp_mode_arg;      // timing experiments (SFMHIP_EXP_DISTMAT; results are wrong with it set)
+#else
+    constexpr int exp_mode = 0;             // release build: the experiment branches below fold away
+    (void)exp_mode_arg;
+#endif
     constexpr int DP = 32 * KS;
     constexpr int CH = DP / 16;
     constexpr int PASSES = (128 * CH) / 256;
@@ -799,6 +806,7 @@ extern "C" {
 
 int sfmhip_descset_create_l2_dev(sfmhip_ctx* ctx, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out);
     SFM_ARG_CHECK(ctx, d_desc && rows >= 0 && dim > 0 && ld >= (size_t)dim);
     sfmhip_descset* s = nullptr;
@@ -812,6 +820,7 @@ int sfmhip_descset_create_l2_dev(sfmhip_ctx* ctx, const float* d_desc, int rows,
 
 int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out);
     SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && dim > 0 && ld >= (size_t)dim);
     float* d = nullptr;
@@ -843,6 +852,7 @@ static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uin
 
 int sfmhip_descset_create_hamming2_dev(sfmhip_ctx* ctx, const uint8_t* d_desc, int rows, int nbytes, size_t ld, sfmhip_descset** out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out);
     SFM_ARG_CHECK(ctx, d_desc && rows >= 0 && nbytes > 0 && nbytes <= 64 && ld >= (size_t)nbytes);
     sfmhip_descset* s = nullptr;
@@ -855,6 +865,7 @@ int sfmhip_descset_create_hamming2_dev(sfmhip_ctx* ctx, const uint8_t* d_desc, i
 
 int sfmhip_descset_create_hamming2_host(sfmhip_ctx* ctx, const uint8_t* desc, int rows, int nbytes, size_t ld, sfmhip_descset** out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out);
     SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && nbytes > 0 && nbytes <= 64 && ld >= (size_t)nbytes);
     uint8_t* d = nullptr;
@@ -876,6 +887,7 @@ int sfmhip_descset_create_hamming2_host(sfmhip_ctx* ctx, const uint8_t* desc, in
 
 void sfmhip_descset_destroy(sfmhip_descset* s)
 {
+    SFM_DEVICE_GUARD(s ? s->ctx : nullptr);
     if (!s) return;
     if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
     if (s->owns_f32 && s->d_f32) (void)hipFree((void*)s->d_f32);
@@ -889,6 +901,7 @@ void sfmhip_descset_destroy(sfmhip_descset* s)
 // re-run the preparation pass on the (possibly rewritten) borrowed float rows; asynchronous, keeps exact_u8
 int sfmhip_descset_refresh(sfmhip_descset* s)
 {
+    SFM_DEVICE_GUARD(s ? s->ctx : nullptr);
     if (!s || !s->ctx) return SFMHIP_E_ARG;
     sfmhip_ctx* ctx = s->ctx;
     if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) return SFMHIP_OK;
@@ -902,6 +915,7 @@ int sfmhip_descset_refresh(sfmhip_descset* s)
 // one launch for many images: what a per-frame "descriptors arrived" step costs when the float rows were rewritten
 int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && (sets || n == 0) && n >= 0);
     std::vector<PrepDesc> tbl;
     int max_pad = 0;
@@ -925,6 +939,7 @@ int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
 
 int sfmhip_descset_info(sfmhip_descset* s, int* kind, int* rows, int* dim, int* exact_u8)
 {
+    SFM_DEVICE_GUARD(s ? s->ctx : nullptr);
     if (!s) return SFMHIP_E_ARG;
     if (kind) *kind = s->kind;
     if (rows) *rows = s->rows;
@@ -1078,6 +1093,7 @@ extern "C" {
 int sfmhip_knn2_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, const sfmhip_descset* train,
                     int32_t* d_idx2, float* d_dist2, int force_path)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && query && train && d_idx2 && d_dist2);
     sfmhip_descset* sets[2] = { (sfmhip_descset*)query, (sfmhip_descset*)train };
     const int32_t pr[2] = { 0, 1 };
@@ -1091,6 +1107,7 @@ int sfmhip_match_pairs_dev(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_s
                            const int32_t* pairs, int n_pairs, double ratio, float floor_, float mult,
                            sfm_dmatch* d_matches, int max_per_pair, int32_t* d_counts)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && d_matches && d_counts && max_per_pair > 0);
     if (n_pairs == 0) return SFMHIP_OK;
     KnnPlan P; KnnWork W;
@@ -1112,6 +1129,7 @@ int sfmhip_match_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets,
                        const int32_t* pairs, int n_pairs, double ratio, float floor_, float mult,
                        sfm_dmatch* matches_out, int max_per_pair, int32_t* counts_out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && matches_out && counts_out && max_per_pair > 0 && n_pairs >= 0);
     if (n_pairs == 0) return SFMHIP_OK;
     sfm_dmatch* d_m = nullptr; int32_t* d_c = nullptr;
@@ -1154,6 +1172,7 @@ static int knn2_host_common(sfmhip_ctx* ctx, sfmhip_descset* qs, sfmhip_descset*
 int sfmhip_knn2_l2_f32(sfmhip_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
                        size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
@@ -1166,6 +1185,7 @@ int sfmhip_knn2_l2_f32(sfmhip_ctx* ctx, const float* q, int nq, const float* t, 
 int sfmhip_knn2_hamming2_u8(sfmhip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
                             size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
@@ -1190,6 +1210,7 @@ static int match_features_common(sfmhip_ctx* ctx, sfmhip_descset* qs, sfmhip_des
 int sfmhip_match_features_l2(sfmhip_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
                              size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
@@ -1202,6 +1223,7 @@ int sfmhip_match_features_l2(sfmhip_ctx* ctx, const float* q, int nq, const floa
 int sfmhip_match_features_hamming2(sfmhip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int nbytes,
                                    size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
@@ -1211,9 +1233,10 @@ int sfmhip_match_features_hamming2(sfmhip_ctx* ctx, const uint8_t* q, int nq, co
     return rc;
 }
 
-// test hook (not part of the public header): number of integers in [0, 2^24) whose sqrt_exact_int differs from sqrtf
-int sfmhip_debug_sqrt_check(sfmhip_ctx* ctx, int* mismatches)
+// self-test (sfmhip.h): number of integers in [0, 2^24) whose sqrt_exact_int differs from sqrtf
+int sfmhip_selftest_exact_sqrt(sfmhip_ctx* ctx, int* mismatches)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && mismatches);
     int* d = nullptr;
     SFM_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(int)));
@@ -1229,6 +1252,7 @@ int sfmhip_debug_sqrt_check(sfmhip_ctx* ctx, int* mismatches)
 int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, const sfmhip_descset* train,
                                   float* d_dist, size_t ld, int force_path)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && query && train && d_dist);
     SFM_ARG_CHECK(ctx, query->kind == SFMHIP_DESC_L2_F32 && train->kind == SFMHIP_DESC_L2_F32 && query->dim == train->dim);
     SFM_ARG_CHECK(ctx, ld >= (size_t)train->rows);
@@ -1236,9 +1260,11 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
     const bool exact = query->exact_u8 && train->exact_u8;
     SFM_ARG_CHECK(ctx, !(force_path == 2 && !exact));
     if (exact && force_path != 1) {
-        const char* em = getenv("SFMHIP_EXP_DISTMAT"); const int exp_mode = em ? atoi(em) : 0;   // timing experiments only
-        const char* eb = getenv("SFMHIP_EXP_BPW");
-        const int bpw = eb ? atoi(eb) : 1;   // 128 trains per workgroup (in-process A/B on MI355X, aligned output: 1: 84 us, 2: 89 us, 4: 93 us, 8: 109 us)
+        int exp_mode = 0, bpw = 1;   // 128 trains per workgroup (in-process A/B on MI355X, aligned output: 1: 84 us, 2: 89 us, 4: 93 us, 8: 109 us)
+#ifdef SFMHIP_EXPERIMENTS
+        if (const char* em = getenv("SFMHIP_EXP_DISTMAT")) exp_mode = atoi(em);
+        if (const char* eb = getenv("SFMHIP_EXP_BPW")) bpw = atoi(eb);
+#endif
         const dim3 grid(query->rows_pad / 128, ceil_div(train->rows_pad / 128, bpw));
         const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
         const int ks = query->dim_pad / 32;

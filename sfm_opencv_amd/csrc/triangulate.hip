@@ -188,6 +188,7 @@ extern "C" {
 int sfmhip_triangulate2_f32_dev(sfmhip_ctx* ctx, const float P1[12], const float P2[12],
                                 const float* d_xy1, const float* d_xy2, int n, float* d_xyzw, double* d_xyz)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && n >= 0);
     if (n == 0) return SFMHIP_OK;
     SFM_ARG_CHECK(ctx, d_xy1 && d_xy2 && (d_xyzw || d_xyz));
@@ -202,6 +203,7 @@ int sfmhip_triangulate2_matches_dev(sfmhip_ctx* ctx, const float P1[12], const f
                                     const sfm_keypoint* d_kp1, const sfm_keypoint* d_kp2,
                                     const sfm_dmatch* d_matches, int n, float* d_xyzw, double* d_xyz)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && n >= 0);
     if (n == 0) return SFMHIP_OK;
     SFM_ARG_CHECK(ctx, d_kp1 && d_kp2 && d_matches && (d_xyzw || d_xyz));
@@ -217,6 +219,7 @@ int sfmhip_triangulate2_matches_dev(sfmhip_ctx* ctx, const float P1[12], const f
 int sfmhip_triangulate2_f32(sfmhip_ctx* ctx, const float P1[12], const float P2[12],
                             const float* xy1, const float* xy2, int n, float* xyzw, double* xyz)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && xy1 && xy2 && n > 0 && (xyzw || xyz));
     float *d1 = nullptr, *d2 = nullptr, *dw = nullptr; double* dx = nullptr;
     int rc = SFMHIP_OK;
@@ -240,6 +243,7 @@ int sfmhip_triangulate_tracks(sfmhip_ctx* ctx, const double K4[4], const double*
                               const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, int n_pt,
                               double* pts_out, int32_t* n_views_out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (pts_out || n_pt == 0));
     SFM_ARG_CHECK(ctx, (obs_cam && obs_pt && obs_uv) || n_obs == 0);
     for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);
@@ -277,6 +281,7 @@ int sfmhip_triangulate_tracks(sfmhip_ctx* ctx, const double K4[4], const double*
 int sfmhip_reprojection_errors(sfmhip_ctx* ctx, const double K4[4], const double* ext6, int n_cam, const double* pts, int n_pt,
                                const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, double* err_out)
 {
+    SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (err_out || n_obs == 0));
     SFM_ARG_CHECK(ctx, n_obs == 0 || (pts && obs_cam && obs_pt && obs_uv));
     for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);

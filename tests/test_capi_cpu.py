@@ -20,6 +20,19 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == declared            # the Python binding covers the whole header
     assert lib.sfmhip_version().startswith(b"sfmhip")
+    # ... and the other direction: the library exports nothing with the sfmhip_ prefix that the header does not declare
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("sfmhip_")})
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+
+
+def test_release_build_has_no_experiment_knobs():
+    """timing / A-B knobs (SFMHIP_EXP_*, solver stamps, ...) exist only in -DSFMHIP_EXPERIMENTS builds"""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for knob in (b"SFMHIP_EXP_", b"SFMHIP_SOLVER_STAMPS", b"SFMHIP_SPECULATE", b"SFMHIP_ND_SEGMENTS", b"SFMHIP_DENSE_SOLVER",
+                 b"SFMHIP_CAM_WG_OBS", b"SFMHIP_SCHUR_CHUNK"):
+        assert knob not in blob, knob
 
 
 def test_struct_layouts_match_the_header():

@@ -173,7 +173,5 @@ def test_exact_sqrt_all_integers(ctx):
     # exhaustive device-side comparison with sqrtf
     import ctypes as C
     n = C.c_int(-1)
-    fn = ctx.lib.sfmhip_debug_sqrt_check
-    fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-    assert fn(ctx.h, C.byref(n)) == 0
+    assert ctx.lib.sfmhip_selftest_exact_sqrt(ctx.h, C.byref(n)) == 0
     assert n.value == 0
