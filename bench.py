@@ -2,7 +2,11 @@
 """bench.py -- headline benchmark of the matching -> BA hot path on MI355X (BASELINE.json metric:
 "BA iterations/sec + matched-pairs/sec, 200-img/300k-pt scene").
 
-    python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: either launched by torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env), or
+run bare -- then this process only spawns the N ranks (before anything touches the GPU), waits, relays rank 0's JSON
+line and exits non-zero if a rank failed.
 
 Workload (config C4 of BASELINE.json, synthetic): 200 images x 5000 integer-valued SIFT-like descriptors
 (199 chain pairs) and a 200-camera / 300k-point / ~1.2M-observation BA scene.  The scene is FIXED as N grows
@@ -29,18 +33,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s measured copy
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x bf16 dense (~2.5 PFLOP/s)
+# TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from separate rocprofv3 --pmc passes over this command at
+# N=1 / C4: recorded figures, NOT measured in the run that prints them (counters are not collectable in-process)
+# a write-only stream on this part (experiments/wbw*.hip, profiles/README.md): what a kernel that only stores can reach
+STORE_CEILING_GBS = 5500.0
+STORE_CEILING_SOURCE = "experiments/wbw2.hip: 400 MB plain-store stream, best of the shapes tried (profiles/README.md)"
+SOLVER_KERNEL = "chol_nd_forward_kernel"
+RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (2.977e8, "profiles/r01_traffic_pmc.md"),
+                    "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md")}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of a parent that never touches the GPU
+    (no torch import, no HIP call), wait for them and relay rank 0's output."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0); sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C4", choices=["C3", "C4", "small"])
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C4", choices=["C3", "C4", "C5", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm", action="store_true")
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--match-steps", type=int, default=0, help="matching passes timed (default: min(steps, 20))")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: the box's cores, at most 16)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -97,16 +135,21 @@ def main():
     b_it = 2 * 24 * n_obs + 2 * 24 * n_pt + 2 * 48 * n_img + 3 * 8 * n_red * n_red
 
     # ------------------------------------------------------------------ region B: matching
-    pairs_g, images, pairs_l = sdist.shard_pairs(n_img, rank, world)
+    # C5 names 1000 images x 10k descriptors (999 pairs, 5 GB of float rows): the chain is generated on the host, so the
+    # bench matches its first 65 images (64 pairs of 10k x 10k x 128) -- the per-pair work is what the size changes
+    n_img_match = min(n_img, 65) if args.config == "C5" else n_img
+    m_steps = args.match_steps if args.match_steps > 0 else min(args.steps, 20)
+    m_warm = min(args.warmup, 3)
+    pairs_g, images, pairs_l = sdist.shard_pairs(n_img_match, rank, world)
     chain = None
     d_desc, sets = [], []
-    if len(images):
+    if len(images) and not args.no_match:
         # descriptors of image i depend on image i-1: generate the chain up to this rank's last image
         chain = synth.sift_descriptor_chain(images[-1] + 1, n_desc)
         for i in images:
             t = torch.from_numpy(chain[i]).cuda()
             d_desc.append(t); sets.append(ctx.descset_l2(t))
-    n_pairs_l = pairs_l.shape[0]
+    n_pairs_l = 0 if args.no_match else pairs_l.shape[0]
     d_matches = torch.zeros((max(n_pairs_l, 1), n_desc, 4), dtype=torch.int32, device="cuda")
     d_counts = torch.zeros((max(n_pairs_l, 1),), dtype=torch.int32, device="cuda")
     h_matches = torch.zeros_like(d_matches, device="cpu").pin_memory()
@@ -120,18 +163,18 @@ def main():
         h_matches.copy_(d_matches, non_blocking=True)
         h_counts.copy_(d_counts, non_blocking=True)
 
-    for _ in range(args.warmup):
+    for _ in range(m_warm):
         match_pass()
     barrier()
     ctx.set_kernel_timing(True)      # HIP events around the kNN kernel of every timed pass, on the library's stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(m_steps):
         match_pass()
     barrier()
     t_match = max_over_ranks(time.perf_counter() - t0)
     knn_kernel_ms, knn_merge_ms, knn_calls, _ = ctx.match_kernel_ms()
     ctx.set_kernel_timing(False)
-    pairs_per_s = (n_img - 1) * args.steps / t_match
+    pairs_per_s = (n_img_match - 1) * m_steps / t_match if not args.no_match else None
     n_matches = int(h_counts.sum().item())
 
     # ------------------------------------------------------------------ materialised 10k x 10k distance matrix
@@ -141,49 +184,73 @@ def main():
         dd = synth.sift_descriptor_chain(2, nq, seed=synth.SEED + 100000)
         q = torch.from_numpy(dd[0]).cuda(); t = torch.from_numpy(dd[1]).cuda()
         qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
-        out = torch.empty((nq, nt), dtype=torch.float32, device="cuda")
-        for _ in range(3):
-            ctx.l2_distance_matrix_dev(qs, ts, out)
-        reps = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(reps):
-            ctx.l2_distance_matrix_dev(qs, ts, out)
-        e1.record(stream); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
         alg = 4.0 * nq * nt + 4.0 * 128 * (nq + nt)          # 410.2 MB
-        gemm = dict(kernel="distmat_i8_kernel<4>", workload="10000x10000x128 float32 distance matrix", ms=ms,
-                    bound="hbm", achieved=alg / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=alg,
-                    traffic=4.378e8)      # TCC WRITE_SIZE + 2 x FETCH_SIZE per launch, profiles/r01_traffic_pmc.md
-        del out, qs, ts
+        legs = {}
+        for name, ld in (("ld_10000", nt), ("ld_10016_rows_128B_aligned", 10016)):
+            buf = torch.empty((nq, ld), dtype=torch.float32, device="cuda")
+            out = buf[:, :nt]
+            for _ in range(3):
+                ctx.l2_distance_matrix_dev(qs, ts, out)
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(reps):
+                ctx.l2_distance_matrix_dev(qs, ts, out)
+            e1.record(stream); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            legs[name] = dict(ms=ms, achieved=alg / (ms * 1e-3) / 1e9, frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              frac_of_store_ceiling=alg / (ms * 1e-3) / 1e9 / STORE_CEILING_GBS)
+            del out, buf
+        ref = legs["ld_10000"]                                # the reference's layout (a dense cv::Mat: row stride = nt)
+        tr, src = RECORDED_TRAFFIC["distmat_i8_kernel<4>"]
+        gemm = dict(kernel="distmat_i8_kernel<4>", workload="10000x10000x128 float32 distance matrix", ms=ref["ms"],
+                    bound="hbm", achieved=ref["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=ref["frac"], algorithmic_bytes=alg,
+                    store_ceiling_gbs=STORE_CEILING_GBS, store_ceiling_source=STORE_CEILING_SOURCE, legs=legs,
+                    traffic=tr, traffic_source=src + " (recorded by separate --pmc passes, not measured in this run)")
+        del qs, ts
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
-    cpu = None
+    cpu = cpu4 = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:      # reported at N=1 only
         import oracle as orc
         cores = args.cpu_threads if args.cpu_threads > 0 else min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
-        orc.set_num_threads(cores)
-        n_it_cpu = 30 if args.config in ("C4", "C5") else 10      # ~10 s of CPU work at C4 (3 it/s on 16 threads)
-        tc = time.perf_counter()
-        orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], force_iterations=n_it_cpu)
-        t_cpu_ba = time.perf_counter() - tc
-        cpu_pairs = min(100, n_img - 1)                               # ~1-2 s: a secondary figure, the metric is BA iterations
-        ch = chain if chain is not None and len(chain) > cpu_pairs else synth.sift_descriptor_chain(cpu_pairs + 1, n_desc)
-        tc = time.perf_counter()
-        for i in range(cpu_pairs):
-            orc.match_features_l2(ch[i], ch[i + 1])
-        t_cpu_m = time.perf_counter() - tc
-        cpu = dict(value=n_it_cpu / t_cpu_ba, unit="it/s", cores=cores, kind="port",
-                   sample=f"{n_it_cpu} forced LM iterations of the same {n_img}-camera/{n_pt}-point scene (incl. one extra "
-                          f"linearisation for the column scaling) and {cpu_pairs} chain pairs of {n_desc}x{n_desc}x128 matching; "
-                          "oracle/ C restatement with OpenMP, not OpenCV/Ceres (unbuildable offline)",
-                   matched_pairs_per_sec=cpu_pairs / t_cpu_m)
+        big = args.config in ("C4", "C5")
+
+        def cpu_ba(threads, n_it):
+            orc.set_num_threads(threads)
+            tc = time.perf_counter()
+            orc.ba_solve(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], force_iterations=n_it)
+            return n_it / (time.perf_counter() - tc)
+
+        def cpu_match(threads, n_pairs_cpu):
+            if args.no_match or n_pairs_cpu <= 0:
+                return None
+            orc.set_num_threads(threads)
+            ch = chain if chain is not None and len(chain) > n_pairs_cpu else synth.sift_descriptor_chain(n_pairs_cpu + 1, n_desc)
+            tc = time.perf_counter()
+            for i in range(n_pairs_cpu):
+                orc.match_features_l2(ch[i], ch[i + 1])
+            return n_pairs_cpu / (time.perf_counter() - tc)
+
+        what = ("forced LM iterations of the same %d-camera/%d-point scene (incl. one extra linearisation for the column "
+                "scaling) and %d chain pairs of %dx%dx128 matching; oracle/ C restatement with OpenMP (an unoptimised "
+                "checker: 13-wide dual-number Jacobians, skyline Cholesky), not OpenCV/Ceres (unbuildable offline)")
+        n_it_cpu = (30 if args.config == "C4" else 6) if big else 10          # ~10 s of CPU work at C4 (3 it/s on 16 threads)
+        cpu_pairs = min(100 if args.config != "C5" else 12, n_img_match - 1)
+        cpu = dict(value=cpu_ba(cores, n_it_cpu), unit="it/s", cores=cores, kind="port",
+                   sample=("%d " % n_it_cpu) + what % (n_img, n_pt, cpu_pairs, n_desc, n_desc),
+                   matched_pairs_per_sec=cpu_match(cores, cpu_pairs))
+        # what the reference asks of Ceres: options.num_threads = 4 (NViewReconstuct.cpp:1218)
+        n_it4 = (10 if args.config == "C4" else 3) if big else 10
+        pairs4 = min(25 if args.config != "C5" else 4, n_img_match - 1)
+        cpu4 = dict(value=cpu_ba(4, n_it4), unit="it/s", cores=4, kind="port",
+                    sample=("%d " % n_it4) + what % (n_img, n_pt, pairs4, n_desc, n_desc),
+                    matched_pairs_per_sec=cpu_match(4, pairs4))
 
     if rank == 0:
-        # single kernels of the LM iteration timed with HIP events inside the library (same stream, timed region):
-        # the largest one is reported as the roofline kernel, the others ride along
+        # single kernels of the LM iteration timed with HIP events inside the library (same stream, instrumented steps):
+        # `roofline` is the one with the largest launch time -- the kernel that dominates the region `value` is measured on
         L = np.bincount(sc["obs_pt"], minlength=n_pt).astype(np.int64)
         n_pairs_items = int((L * (L - 1) // 2).sum())
         kern = {
@@ -191,51 +258,51 @@ def main():
                                     what="per observation pair: 8 B pair record + 24 B point + 24 B scale + 48 B V^-1 + 2x16 B pixels"),
             "ba_camera_kernel": dict(ms=phase[4], bytes=n_obs * (4 + 16 + 24 + 24 + 48 + 24 + 96),
                                      what="per observation: 20 B record + 24 B point + 24 B scale + 48 B V^-1 + 24 B b + 96 B W_K"),
-            "chol_nd_forward_kernel": dict(ms=phase[6], bytes=2 * 8 * 1024 * phase[7],
-                                           what="non-zero 32x32 blocks of S read and of L written"),
+            SOLVER_KERNEL: dict(ms=phase[6], bytes=2 * 8 * 1024 * phase[7],
+                                what="non-zero 32x32 blocks of S read and of L written"),
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
         kd = kern[dom]
-        roof_ba = {"kernel": dom, "bound": "hbm", "achieved": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9,
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                   "traffic": None, "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
-                   "note": f"largest kernel of one LM iteration; every BA kernel is latency-bound at this size ({phase[3]:.2f} ms of device time "
-                           f"for {b_it / 1e6:.0f} MB), see DESIGN.md 7"}
-        # the kernel with the most GPU time of the whole bench step: the fused int8 kNN-2 kernel of the matching pass
-        roof = roof_ba
+        roof = {"kernel": dom, "bound": "hbm", "achieved": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
+                "note": f"largest kernel of one LM iteration (the region `value` is measured on); the iteration is latency-bound at this size "
+                        f"({phase[3]:.3f} ms of device time for {b_it / 1e6:.0f} MB), see roofline_lm_iteration and DESIGN.md 7"}
+        roof_knn = None
         if n_pairs_l and knn_calls:
             ops = 2.0 * n_desc * n_desc * 128 * n_pairs_l       # 2 * nq * nt * dim per pair
-            # TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of one launch, separate --pmc passes of this command at
-            # N=1 / C4 (profiles/r01_traffic_pmc.md); not collectable from inside the process
-            traffic = 2.977e8 if (world == 1 and args.config == "C4") else None
-            roof = {"kernel": "knn2_i8_kernel<4>", "bound": "mfma", "achieved": ops / (knn_kernel_ms * 1e-3) / 1e12,
-                    "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ops / (knn_kernel_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                    "traffic": traffic, "traffic_unit": "bytes per launch, L2 fabric side: 2 x FETCH_SIZE + WRITE_SIZE (operands 255 MB + 32 MB of partial keys; 1,092 MB before the pair -> XCD mapping)", "algorithmic_ops": ops, "avg_launch_ms": knn_kernel_ms, "launches_timed": int(knn_calls),
-                    "merge_rescore_ms": knn_merge_ms,
-                    "note": "one launch = all chain pairs of this rank; peak = dense int8 MFMA at 2.4 GHz (measured sustained "
-                            "4.2 POP/s, experiments/mfma_i8_bench.hip); the top-2 epilogue (3 VALU ops per distance) bounds "
-                            "this kernel at ~0.55 ms, see DESIGN.md 7"}
+            tr, src = RECORDED_TRAFFIC["knn2_i8_kernel<4>"] if (world == 1 and args.config == "C4") else (None, None)
+            roof_knn = {"kernel": "knn2_i8_kernel<4>", "bound": "mfma", "achieved": ops / (knn_kernel_ms * 1e-3) / 1e12,
+                        "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ops / (knn_kernel_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                        "traffic": tr, "traffic_source": (src + " (recorded by separate --pmc passes, not measured in this run)") if src else None,
+                        "traffic_unit": "bytes per launch, L2 fabric side: 2 x FETCH_SIZE + WRITE_SIZE",
+                        "algorithmic_ops": ops, "avg_launch_ms": knn_kernel_ms, "launches_timed": int(knn_calls),
+                        "merge_rescore_ms": knn_merge_ms,
+                        "note": "one launch = all chain pairs of this rank; peak = dense int8 MFMA at 2.4 GHz (measured sustained "
+                                "4.2 POP/s, experiments/mfma_i8_bench.hip)"}
         out = {
             "metric": "ba_iterations_per_sec", "value": ba_its, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_ba / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img - 1} chain pairs), "
+            "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img_match - 1} chain pairs matched), "
                                    f"{n_img} cameras / {n_pt} points / {n_obs} observations BA",
                        "parallelism": f"points+pairs sharded over {world} rank(s), cameras replicated, 1 all-reduce/iteration",
                        "reduced_system_order": n_red},
             "roofline": roof,
-            "roofline_ba": roof_ba,
             "roofline_lm_iteration": {"bound": "hbm", "achieved": b_it / (phase[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": b_it / (phase[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b_it, "device_ms": phase[3]},
+            "roofline_knn": roof_knn,
             "ba_kernel_ms": {k: v["ms"] for k, v in kern.items()},
             "ba_phase_ms": {"linearize_schur": phase[0], "reduced_solve": phase[1], "backsub_cost": phase[2], "total_device": phase[3],
                             "measured": f"HIP events over {args.steps} further steps after the timed ones (instrumentation off during the timed steps)"},
             "ba_cost": {"initial": (s0 or s1)["initial_cost"], "after_timed_steps": s1["final_cost"],
                         "successful_steps": s1["successful_steps"], "iterations": s1["iterations"]},
-            "matched_pairs_per_sec": {"value": pairs_per_s, "ms_per_pass": 1e3 * t_match / args.steps, "pairs": n_img - 1,
-                                      "matches_rank0": n_matches, "includes": "prep + kNN-2 + ratio tail + D2H of match lists"},
+            "matched_pairs_per_sec": None if args.no_match else
+                {"value": pairs_per_s, "ms_per_pass": 1e3 * t_match / m_steps, "pairs": n_img_match - 1, "passes_timed": m_steps,
+                 "matches_rank0": n_matches, "includes": "prep + kNN-2 + ratio tail + D2H of match lists"},
             "roofline_gemm": gemm,
             "cpu_baseline": cpu,
+            "cpu_baseline_4thr": cpu4,
         }
         print(json.dumps(out))
     if world > 1:

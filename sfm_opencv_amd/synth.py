@@ -98,15 +98,25 @@ def angle_axis_to_rotmat(aa):
     return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
 
 
+def _cross(a, b):
+    """np.cross for (m,3) arrays, same arithmetic (one multiply pair and a subtract per component), without its overhead"""
+    out = np.empty_like(b)
+    out[:, 0] = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
+    out[:, 1] = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
+    out[:, 2] = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    return out
+
+
 def project(K4, ext6, X):
     """ReprojectCost's forward model (NViewReconstuct.cpp:151-177) for arrays: ext6 (m,6), X (m,3) -> (m,2)."""
     aa = ext6[:, :3]; t = ext6[:, 3:]
-    th = np.linalg.norm(aa, axis=1, keepdims=True)
+    th = np.sqrt((aa[:, 0] * aa[:, 0] + aa[:, 1] * aa[:, 1] + aa[:, 2] * aa[:, 2]))[:, None]
     safe = np.where(th > 0, th, 1.0)
     w = aa / safe
     c = np.cos(th); s = np.sin(th)
-    p = X * c + np.cross(w, X) * s + w * (np.sum(w * X, axis=1, keepdims=True) * (1 - c))
-    p = np.where(th * th > np.finfo(np.float64).eps, p, X + np.cross(aa, X)) + t
+    wx = (w[:, 0] * X[:, 0] + w[:, 1] * X[:, 1] + w[:, 2] * X[:, 2])[:, None]
+    p = X * c + _cross(w, X) * s + w * (wx * (1 - c))
+    p = np.where(th * th > np.finfo(np.float64).eps, p, X + _cross(aa, X)) + t
     return np.stack([K4[0] * p[:, 0] / p[:, 2] + K4[2], K4[1] * p[:, 1] / p[:, 2] + K4[3]], axis=1)
 
 

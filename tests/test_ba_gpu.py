@@ -141,21 +141,19 @@ def test_allreduce_hook_identity_and_failure(ctx):
         bad.iterate(1)
 
 
-def test_two_point_shards_on_one_gpu_match_unsharded(ctx):
-    """SURVEY 8e on a single card: two contexts, each with half of the points, driven by two threads whose
-    all-reduce hook sums the two libraries' packed messages -- the N>1 data path (packed non-zero blocks through the
-    hook, replicated solve, sharded back-substitution) against the unsharded solve."""
+def _run_sharded_on_one_gpu(sc, n_iter, world=2, opts_of_rank=None):
+    """SURVEY 8e on a single card: `world` contexts, each with a shard of the points, driven by `world` threads whose
+    all-reduce hook sums the libraries' packed messages -- the N>1 data path (packed non-zero blocks through the hook,
+    replicated solve, sharded back-substitution).  Returns (summaries, params, point ids, message sizes) per rank."""
     import threading
     import torch
     from sfm_opencv_amd import dist as sdist
-    sc = synth.ba_scene(24, 4000)
-    ref = ctx.ba_create(*_args(sc)); sr = ref.iterate(5); Kr, extr, ptsr = ref.params()
-    world = 2
     ctxs = [api.Context(0, use_torch_stream=False) for _ in range(world)]
     probs, ids = [], []
     for r in range(world):
         pts_l, oc, op, uv, pid = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], r, world)
-        probs.append(ctxs[r].ba_create(sc["K0"], sc["ext0"], pts_l, oc, op, uv)); ids.append(pid)
+        o = ctxs[r].ba_options(**(opts_of_rank(r) if opts_of_rank else {}))
+        probs.append(ctxs[r].ba_create(sc["K0"], sc["ext0"], pts_l, oc, op, uv, opts=o)); ids.append(pid)
     bar = threading.Barrier(world)
     slots = [None] * world
     counts = [[] for _ in range(world)]
@@ -167,8 +165,11 @@ def test_two_point_shards_on_one_gpu_match_unsharded(ctx):
             counts[r].append(count)
             bar.wait()
             if r == 0:
-                total = slots[0] + slots[1]
-                slots[0].copy_(total); slots[1].copy_(total)
+                total = slots[0].clone()
+                for q in range(1, world):
+                    total += slots[q]
+                for q in range(world):
+                    slots[q].copy_(total)
                 torch.cuda.synchronize()
             bar.wait()
             return 0
@@ -179,25 +180,49 @@ def test_two_point_shards_on_one_gpu_match_unsharded(ctx):
     def run(r):
         try:
             probs[r].set_allreduce(make_hook(r), r, world)
-            out[r] = probs[r].iterate(5)
+            out[r] = probs[r].iterate(n_iter)
         except Exception as e:                                      # pragma: no cover
             errs.append(e); bar.abort()
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th: t.start()
-    for t in th: t.join(120)
-    assert not errs and all(o is not None for o in out)
+    for t in th: t.join(180)
+    assert not errs and all(o is not None for o in out), errs
+    params = [pb.params() for pb in probs]
+    for pb in probs: pb.close()
+    for c in ctxs: c.close()
+    return out, params, ids, counts
+
+
+@pytest.mark.parametrize("shape", [(24, 4000), (120, 12000)])
+def test_two_point_shards_on_one_gpu_match_unsharded(ctx, shape):
+    """Two point shards against the unsharded solve.  (120 cameras: the multi-segment solver path with the hook.)"""
+    sc = synth.ba_scene(*shape)
+    ref = ctx.ba_create(*_args(sc)); sr = ref.iterate(5); Kr, extr, ptsr = ref.params()
+    out, params, ids, counts = _run_sharded_on_one_gpu(sc, 5)
     assert counts[0] == counts[1] and len(counts[0]) >= 10
     n_red = 6 * (sc["n_cam"] - 1) + 4
     assert max(counts[0]) < n_red * n_red                           # packed: fewer doubles than the dense square
-    for r in range(world):
+    for r in range(2):
         assert out[r]["iterations"] == sr["iterations"] and out[r]["successful_steps"] == sr["successful_steps"]
         assert abs(out[r]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
-        K, ext, pts = probs[r].params()
+        K, ext, pts = params[r]
         assert np.abs(ext - extr).max() <= 1e-9 and np.abs(K - Kr).max() <= 1e-9 * np.abs(Kr).max()
         assert np.abs(pts - ptsr[ids[r]]).max() <= 1e-9
-    for pb in probs: pb.close()
-    for c in ctxs: c.close()
+
+
+def test_sharded_error_flag_is_shared_by_all_ranks():
+    """A rank whose shard trips the point kernel's error flag (non-SPD V of a LOCAL point) must not take a different
+    accept / invalid branch than its peers (replicated cameras, radius and nu would diverge and the next all-reduce
+    hang).  Injection: rank 1 damps its points with a negative max_lm_diagonal, so every V of its shard fails the
+    Cholesky while the cost stays finite; rank 0's shard is healthy.  Every rank must count the same invalid steps."""
+    sc = synth.ba_scene(24, 4000)
+    out, params, ids, counts = _run_sharded_on_one_gpu(sc, 3, opts_of_rank=lambda r: dict(max_lm_diagonal=-1.0) if r == 1 else {})
+    assert out[0]["iterations"] == out[1]["iterations"] == 3
+    assert out[0]["successful_steps"] == out[1]["successful_steps"] == 0       # every step invalid on BOTH ranks
+    assert out[0]["final_radius"] == out[1]["final_radius"]                    # both halved the radius three times
+    for r in range(2):
+        assert np.array_equal(params[r][1], sc["ext0"])                        # no rank moved its camera replicas
 
 
 def test_bundle_adjustment_wrapper_in_place(ctx, capsys):

@@ -1,6 +1,9 @@
-"""Parity at BASELINE.json's full sizes (C4 per-pair 5000 x 5000 x 128, the 10k x 10k roofline case, the 200-camera /
-300k-point BA scene) through size-independent properties plus oracle spot checks on slices the oracle finishes in
-seconds.  Everything goes through the C-ABI."""
+"""Parity at BASELINE.json's full sizes (C3's 50-camera / 80k-point BA scene, C4 per-pair 5000 x 5000 x 128 and its
+200-camera / 300k-point scene, C5's 10k x 10k pair and its 1000-camera / 2M-point / 8M-observation scene, normals of a
+300k-point cloud) through size-independent properties plus oracle checks where the oracle finishes in about a minute.
+Everything goes through the C-ABI."""
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -156,3 +159,130 @@ def test_kernel_timing_api_and_full_size_tracks(ctx):
     assert np.abs(pts - sc["pts_true"]).max() < 1e-7
     err = ctx.reprojection_errors(sc["K_true"], sc["ext_true"], pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
     assert err.max() < 1e-6
+
+
+def test_c3_bundle_adjustment_scene(ctx):
+    """BASELINE.json configs[2]: 50 cameras / 80k points / ~320k observations (n = 298): the reduced system and six forced
+    LM steps against the oracle, same bars as the small-scene tests."""
+    cfg = synth.CONFIGS["C3"]
+    sc = synth.ba_scene(cfg["n_img"], cfg["n_pt"])
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    orc.set_num_threads(16)
+    pb = ctx.ba_create(*args)
+    S, rhs, cost = pb.reduced_system(1e4)
+    So, rhso, costo = orc.ba_reduced_system(*args, 1e4)
+    assert S.shape == (298, 298) and abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(rhs - rhso).max() <= 1e-9 * np.abs(rhso).max()
+    s = pb.iterate(6)
+    K, ext, pts = pb.params()
+    Ko, exto, ptso, so, _ = orc.ba_solve(*args, force_iterations=6)
+    assert s["iterations"] == so["iterations"] == 6 and s["successful_steps"] == so["successful_steps"]
+    assert abs(s["initial_cost"] - so["initial_cost"]) <= 1e-12 * so["initial_cost"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    assert np.abs(ext - exto).max() <= 1e-6 * 10.0 and np.abs(K - Ko).max() <= 1e-6 * 3000.0
+    assert np.quantile(np.abs(pts - ptso).max(axis=1), 0.999) <= 1e-6 * 10.0
+    pb.close()
+
+
+def test_c5_pair_knn_oracle_slice(ctx):
+    """BASELINE.json configs[4] per-pair size: 10k x 10k x 128 fused kNN-2 + ratio tail; oracle on a 200-row query slice."""
+    d = synth.sift_descriptor_chain(2, 10000, seed=31337)
+    a, b = d[0], d[1]
+    gi, gd = ctx.knn2_l2(a, b)
+    rows = np.random.default_rng(12).choice(10000, 200, replace=False)
+    oi, od = orc.knn2_l2(a[rows], b)
+    assert np.array_equal(gi[rows], oi) and np.array_equal(gd[rows].view(np.uint32), od.view(np.uint32))
+    m = api.match_features(a, b, ctx=ctx)
+    ref = api.ratio_filter(gi, gd)
+    assert len(m) > 4000 and np.array_equal(m, ref)
+    # a permutation of the train rows permutes the answer
+    perm = np.random.default_rng(13).permutation(10000)
+    gi2, gd2 = ctx.knn2_l2(a, b[perm])
+    assert np.array_equal(gd.view(np.uint32), gd2.view(np.uint32))
+    clean = gd[:, 0] != gd[:, 1]
+    assert np.array_equal(perm[gi2[clean]], gi[clean])
+
+
+@pytest.fixture(scope="module")
+def c5_scene():
+    cfg = synth.CONFIGS["C5"]
+    t0 = time.time()
+    sc = synth.ba_scene(cfg["n_img"], cfg["n_pt"])
+    print(f"[c5] scene generated in {time.time() - t0:.1f} s: {sc['n_obs']} observations")
+    return sc
+
+
+def test_c5_bundle_adjustment_full_size(ctx, c5_scene):
+    """BASELINE.json configs[4] on ONE GPU: 1000 cameras / 2M points / ~8M observations, n = 5998 (S dense = 288 MB).
+    (1) one linearisation against the oracle on 16 threads; (2) monotone LM trajectory down to the noise floor;
+    (3) bitwise-identical rerun."""
+    sc = c5_scene
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    t0 = time.time()
+    pb = ctx.ba_create(*args)
+    t_create = time.time() - t0
+    S, rhs, cost = pb.reduced_system(1e4)
+    assert S.shape == (5998, 5998)
+    orc.set_num_threads(16)
+    t0 = time.time()
+    So, rhso, costo = orc.ba_reduced_system(*args, 1e4)
+    print(f"[c5] ba_create {t_create:.1f} s, oracle linearisation {time.time() - t0:.1f} s")
+    assert abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(rhs - rhso).max() <= 1e-9 * np.abs(rhso).max()
+    del So, rhso, S
+    costs = [pb.iterate(1)["final_cost"] for _ in range(10)]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    assert np.sqrt(costs[-1] / (2 * sc["n_obs"])) < 2.5
+    K, ext, pts = pb.params()
+    pb.reset(); pb.iterate(10)
+    K2, ext2, pts2 = pb.params()
+    assert np.array_equal(K, K2) and np.array_equal(ext, ext2) and np.array_equal(pts, pts2)
+    pb.close()
+
+
+def test_c5_point_shards_add_up(ctx, c5_scene):
+    """the multi-GPU contract at C5's size: the partial reduced systems of four point shards sum to the full one"""
+    sc = c5_scene
+    o = ctx.ba_options(jacobi_scaling=0)
+    full = ctx.ba_create(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], opts=o)
+    Sf, rf, cf = full.reduced_system(-1e4)
+    full.close()
+    acc_r = np.zeros_like(rf); acc_c = 0.0
+    acc_S = np.zeros_like(Sf)
+    for r in range(4):
+        pl, oc, op, uv, ids = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], r, 4)
+        sh = ctx.ba_create(sc["K0"], sc["ext0"], pl, oc, op, uv, opts=o)
+        Ss, rs, cs = sh.reduced_system(-1e4)
+        acc_S += Ss; acc_r += rs; acc_c += cs
+        sh.close(); del Ss
+    assert abs(acc_c - cf) <= 1e-11 * cf
+    assert np.abs(acc_S - Sf).max() <= 1e-10 * np.abs(Sf).max() and np.abs(acc_r - rf).max() <= 1e-10 * max(np.abs(rf).max(), 1e-300)
+
+
+def test_normals_at_300k_points(ctx):
+    """estimate_normals (NView:551-599) at the C4 point count, where the reference's O(N^2 log N) host loop is unusable:
+    (1) 400 random rows against a numpy restatement of the same rule (10 nearest other points by Euclidean distance,
+    plane fit, flip towards the origin side); (2) on a noisy sphere the normals are radial and point inwards."""
+    rng = np.random.default_rng(77)
+    n = 300_000
+    d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = d * (5.0 + 0.002 * rng.standard_normal((n, 1))) + np.array([0.3, -0.2, 0.1])
+    t0 = time.time()
+    nrm = ctx.estimate_normals(pts, 10)
+    dt = time.time() - t0
+    print(f"[normals] 300k points, K=10: {dt * 1e3:.0f} ms incl. H2D/D2H")
+    assert np.isfinite(nrm).all() and np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-12
+    rows = rng.choice(n, 400, replace=False)
+    for i in rows:
+        dist = np.sqrt(((pts - pts[i]) ** 2).sum(1)); dist[i] = np.inf
+        nb = np.argsort(dist, kind="stable")[:10]
+        q = pts[nb]; mean = q.mean(0)
+        C = (q - mean).T @ (q - mean) / 10.0
+        w, V = np.linalg.eigh(C)
+        v = V[:, 0]
+        if v @ mean > 0:
+            v = -v
+        assert np.abs(nrm[i] - v).max() <= 1e-7, i           # eigenvector conditioning: gap / eps
+    radial = -(pts - np.array([0.3, -0.2, 0.1])) / np.linalg.norm(pts - np.array([0.3, -0.2, 0.1]), axis=1, keepdims=True)
+    cosang = (nrm * radial).sum(1)
+    assert np.quantile(cosang, 0.01) > 0.95
