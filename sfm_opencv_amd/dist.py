@@ -81,12 +81,17 @@ def make_allreduce_hook(group=None, device="cuda"):
 
     import torch
     import torch.distributed as dist
+    # (address, count) -> tensor view.  The views own nothing (raw address + length): one that outlives the buffer it was
+    # made for is harmless, and if a later buffer lands on the same address with the same length the view IS that buffer.
+    # The library reduces at most three distinct buffers per problem; bounded anyway.
     cache = {}
 
     def hook(ptr, count, stream):
         key = (ptr, count)
         t = cache.get(key)
         if t is None:
+            if len(cache) >= 64:
+                cache.clear()
             if device == "cpu":
                 buf = (ctypes.c_double * count).from_address(ptr)
                 t = torch.from_numpy(np.frombuffer(buf, np.float64, count))

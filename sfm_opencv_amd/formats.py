@@ -39,6 +39,24 @@ def _dtoa(v):
     return "%se%s%02d" % (format(q, "f"), "+" if exp10 >= 0 else "-", abs(exp10))
 
 
+def _ftoa(v):
+    """fs::floatToString(buf, value, halfprecision=false, explicitZero=false) [3P]: "%.8e" of a float32"""
+    v = float(np.float32(v))
+    if np.isnan(v):
+        return ".Nan"
+    if np.isinf(v):
+        return "-.Inf" if v < 0 else ".Inf"
+    if abs(v) < 2 ** 31 and float(int(round(v))) == v:
+        return "%d." % int(round(v))
+    d = Decimal(v)
+    exp10 = d.adjusted()
+    q = d.scaleb(-exp10).quantize(Decimal(1).scaleb(-8), rounding=ROUND_HALF_UP)
+    if abs(q) >= 10:
+        exp10 += 1
+        q = d.scaleb(-exp10).quantize(Decimal(1).scaleb(-8), rounding=ROUND_HALF_UP)
+    return "%se%s%02d" % (format(q, "f"), "+" if exp10 >= 0 else "-", abs(exp10))
+
+
 class _Emitter:
     def __init__(self):
         self.lines = []
@@ -84,6 +102,30 @@ def structure_yml_text(rotations, motions, points, colors):
     e.lines.append("Points:")
     for p in np.asarray(points, np.float64).reshape(-1, 3):
         e.flow_seq("   - ", [_dtoa(v) for v in p], 7)
+    e.lines.append("Colors:")
+    for c in np.asarray(colors).reshape(-1, 3):
+        e.flow_seq("   - ", ["%d" % int(v) for v in c], 7)
+    return "\n".join(e.lines) + "\n"
+
+
+def structure_yml_text_twoview(rotations, motions, structure_h, colors):
+    """TwoViewReconstruct.cpp:313-356: `structure_h` is the homogeneous 4 x N float32 matrix of cv::triangulatePoints; every
+    column is divided by its w in float32 (Mat_<float> c; c /= c(3): product with the double reciprocal, rounded to float
+    [3P]) and written as a Point3f ("%.8e")."""
+    e = _Emitter()
+    h = np.asarray(structure_h, np.float32).reshape(4, -1)
+    e.lines += ["%YAML:1.0", "---", "Camera Count: %d" % len(rotations), "Point Count: %d" % h.shape[1]]
+    for name, ms, rows, cols in (("Rotations", rotations, 3, 3), ("Motions", motions, 3, 1)):
+        e.lines.append(name + ":")
+        for m in ms:
+            m = np.asarray(m, np.float64).reshape(rows, cols)
+            e.lines += ["   - !!opencv-matrix", "      rows: %d" % rows, "      cols: %d" % cols, "      dt: d"]
+            e.flow_seq("      data: ", [_dtoa(v) for v in m.reshape(-1)], 10)
+    e.lines.append("Points:")
+    rw = 1.0 / h[3].astype(np.float64)
+    xyz = (h[:3].astype(np.float64) * rw).astype(np.float32)
+    for i in range(h.shape[1]):
+        e.flow_seq("   - ", [_ftoa(v) for v in xyz[:, i]], 7)
     e.lines.append("Colors:")
     for c in np.asarray(colors).reshape(-1, 3):
         e.flow_seq("   - ", ["%d" % int(v) for v in c], 7)

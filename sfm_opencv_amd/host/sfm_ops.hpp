@@ -150,6 +150,22 @@ inline int reconstruct(const Mat& K, Mat& R1, Mat& T1, Mat& R2, Mat& T2, std::ve
     return 0;
 }
 
+// TwoViewReconstruct.cpp:231-250: first camera at the origin (proj1 = float(K) [I | 0]), second [R | T]; the result stays
+// HOMOGENEOUS -- `structure` is the 4 x N CV_32F matrix cv::triangulatePoints fills (one column per point); the division
+// by w happens when the file is written (TwoViewReconstruct.cpp:341-346).  void like the reference: errors only print.
+inline void reconstruct(Mat& K, Mat& R, Mat& T, std::vector<Point2f>& p1, std::vector<Point2f>& p2, Mat& structure)
+{
+    const int n = (int)p1.size();
+    structure = Mat(4, n, CV_32F);
+    sfmhip_ctx* ctx = context();
+    if (!ctx || n == 0 || p2.size() != p1.size()) { if (n == 0) structure = Mat(); return; }
+    Mat R0 = Mat::eye3(), T0(3, 1, CV_64F);
+    float P1[12], P2[12];
+    projection_matrix(K, R0, T0, P1); projection_matrix(K, R, T, P2);
+    const int rc = sfmhip_triangulate2_f32(ctx, P1, P2, &p1[0].x, &p2[0].x, n, structure.ptr<float>(), nullptr);
+    if (rc != SFMHIP_OK) { printf("[Err]: reconstruct: %s\n", sfmhip_last_error(ctx)); structure = Mat(); }
+}
+
 // ---- track bookkeeping (host, integer; NView:959-983, 1246-1301) --------------------------------------------------
 inline void init_correspondence(const std::vector<std::vector<KeyPoint>>& key_points_for_all, const std::vector<DMatch>& matches01,
                                 const std::vector<uint8_t>& mask, std::vector<std::vector<int>>& correspond_struct_idx)
@@ -224,6 +240,20 @@ inline void Rodrigues(const Mat& R, Mat& r)
     for (int i = 0; i < 3; ++i) r.at<double>(i) = s * w[i];
 }
 
+// cv::Rodrigues 3x1 -> 3x3 (NView:1418): R = cos(th) I + (1 - cos(th)) r r' + sin(th) [r]x, r = v / |v| [3P]
+inline void Rodrigues_vec(const Mat& rvec, Mat& R)
+{
+    R = Mat::eye3();
+    const double x = rvec.at<double>(0), y = rvec.at<double>(1), z = rvec.at<double>(2);
+    const double th = std::sqrt(x * x + y * y + z * z);
+    if (th < 2.220446049250313e-16) return;
+    const double c = std::cos(th), s = std::sin(th), c1 = 1.0 - c, rx = x / th, ry = y / th, rz = z / th;
+    double* m = R.ptr<double>();
+    m[0] = c + c1 * rx * rx;       m[1] = c1 * rx * ry - s * rz;  m[2] = c1 * rx * rz + s * ry;
+    m[3] = c1 * rx * ry + s * rz;  m[4] = c + c1 * ry * ry;       m[5] = c1 * ry * rz - s * rx;
+    m[6] = c1 * rx * rz - s * ry;  m[7] = c1 * ry * rz + s * rx;  m[8] = c + c1 * rz * rz;
+}
+
 // ---- bundle adjustment (NView:1162-1244): in place on intrinsic (4x1), extrinsics (6x1 each), structure -----------
 inline void bundle_adjustment(Mat& intrinsic, std::vector<Mat>& extrinsics, std::vector<std::vector<int>>& inds_2d_to_3d,
                               std::vector<std::vector<KeyPoint>>& key_points_for_all, std::vector<Point3d>& pts3d)
@@ -267,12 +297,28 @@ inline int estimate_normals(const std::vector<Point3d>& pts3d, const int K, std:
 namespace detail {
 // fs::doubleToString [3P] + the "%.16e" of the Windows CRT the reference's files were written with (exact decimal ties
 // round half away from zero; glibc rounds them to even)
+// fs::floatToString [3P]: "%.8e" of the float (integral values as "3."), same CRT rounding rule
+inline std::string etoa(double v, int frac_digits);
+inline std::string ftoa(float v)
+{
+    char buf[64];
+    if (std::isnan(v)) return ".Nan";
+    if (std::isinf(v)) return v < 0 ? "-.Inf" : ".Inf";
+    if (std::fabs(v) < 2147483648.0f && (float)(long long)std::llround((double)v) == v) { snprintf(buf, sizeof buf, "%lld.", (long long)std::llround((double)v)); return buf; }
+    return etoa((double)v, 8);
+}
 inline std::string dtoa(double v)
 {
     char buf[512];
     if (std::isnan(v)) return ".Nan";
     if (std::isinf(v)) return v < 0 ? "-.Inf" : ".Inf";
     if (std::fabs(v) < 2147483648.0 && (double)(long long)std::llround(v) == v) { snprintf(buf, sizeof buf, "%lld.", (long long)std::llround(v)); return buf; }
+    return etoa(v, 16);
+}
+// "%.<frac_digits>e" with exact decimal ties rounded half away from zero
+inline std::string etoa(double v, int frac_digits)
+{
+    char buf[512];
     snprintf(buf, sizeof buf, "%.60e", v);          // glibc prints the exact expansion
     std::string s(buf);
     const size_t epos = s.find('e');
@@ -281,14 +327,15 @@ inline std::string dtoa(double v)
     if (neg) mant = mant.substr(1);
     std::string digits; digits += mant[0]; digits += mant.substr(2);          // d.ddddd -> "ddddd..."
     int e10 = std::atoi(ex.c_str());
-    const bool up = digits[17] >= '5';                                          // >= half -> away from zero (exact ties included)
-    std::string d17 = digits.substr(0, 17);
+    const int nd = frac_digits + 1;
+    const bool up = digits[nd] >= '5';                                          // >= half -> away from zero (exact ties included)
+    std::string dn = digits.substr(0, nd);
     if (up) {
-        int i = 16;
-        while (i >= 0) { if (d17[i] == '9') { d17[i] = '0'; --i; } else { d17[i]++; break; } }
-        if (i < 0) { d17 = "1" + d17.substr(0, 16); ++e10; }
+        int i = nd - 1;
+        while (i >= 0) { if (dn[i] == '9') { dn[i] = '0'; --i; } else { dn[i]++; break; } }
+        if (i < 0) { dn = "1" + dn.substr(0, nd - 1); ++e10; }
     }
-    snprintf(buf, sizeof buf, "%s%c.%se%c%02d", neg ? "-" : "", d17[0], d17.substr(1).c_str(), e10 < 0 ? '-' : '+', e10 < 0 ? -e10 : e10);
+    snprintf(buf, sizeof buf, "%s%c.%se%c%02d", neg ? "-" : "", dn[0], dn.substr(1).c_str(), e10 < 0 ? '-' : '+', e10 < 0 ? -e10 : e10);
     return buf;
 }
 struct Emitter {
@@ -328,6 +375,40 @@ inline void save_structure(std::string file_name, std::vector<Mat>& rotations, s
     mats("Rotations", rotations); mats("Motions", motions);
     e.line("Points:");
     for (const auto& p : structure) e.flow("   - ", { detail::dtoa(p.x), detail::dtoa(p.y), detail::dtoa(p.z) }, 7);
+    e.line("Colors:");
+    for (const auto& c : colors) e.flow("   - ", { std::to_string(c[0]), std::to_string(c[1]), std::to_string(c[2]) }, 7);
+    std::ofstream f(file_name, std::ios::out | std::ios::binary);
+    f << e.out;
+}
+
+// TwoViewReconstruct.cpp:313-356: `structure` is the homogeneous 4 x N float matrix; each column is divided by its w in
+// float32 (Mat_<float> c; c /= c(3)) and written as a Point3f, i.e. "%.8e" tokens (fs::floatToString [3P])
+inline void save_structure(std::string file_name, std::vector<Mat>& rotations, std::vector<Mat>& motions, Mat& structure,
+                           std::vector<Vec3b>& colors)
+{
+    detail::Emitter e;
+    e.line("%YAML:1.0"); e.line("---");
+    e.line("Camera Count: " + std::to_string(rotations.size()));
+    e.line("Point Count: " + std::to_string(structure.cols));
+    auto mats = [&](const char* name, std::vector<Mat>& ms) {
+        e.line(std::string(name) + ":");
+        for (auto& m : ms) {
+            e.line("   - !!opencv-matrix"); e.line("      rows: " + std::to_string(m.rows)); e.line("      cols: " + std::to_string(m.cols)); e.line("      dt: d");
+            std::vector<std::string> tok;
+            for (int i = 0; i < m.rows * m.cols; ++i) tok.push_back(detail::dtoa(m.ptr<double>()[i]));
+            e.flow("      data: ", tok, 10);
+        }
+    };
+    mats("Rotations", rotations); mats("Motions", motions);
+    e.line("Points:");
+    for (int i = 0; i < structure.cols; ++i) {
+        const float w = structure.at<float>(3, i);
+        // cv::Mat /= scalar multiplies by the reciprocal taken in double and rounds to float [3P]
+        const double rw = 1.0 / (double)w;
+        const float x = (float)((double)structure.at<float>(0, i) * rw), y = (float)((double)structure.at<float>(1, i) * rw),
+                    z = (float)((double)structure.at<float>(2, i) * rw);
+        e.flow("   - ", { detail::ftoa(x), detail::ftoa(y), detail::ftoa(z) }, 7);
+    }
     e.line("Colors:");
     for (const auto& c : colors) e.flow("   - ", { std::to_string(c[0]), std::to_string(c[1]), std::to_string(c[2]) }, 7);
     std::ofstream f(file_name, std::ios::out | std::ios::binary);

@@ -1,0 +1,258 @@
+// sfm_pipeline.hpp -- what the reference's main() does around the hot path (NViewReconstuct.cpp:1334-1524), on the host
+// mirror of sfm_ops.hpp / sfm_geometry.hpp.  Used by the two driver programs NViewReconstruct.cpp / TwoViewReconstruct.cpp.
+//
+// Input: the reference reads a directory of .jpg files and runs cv::AKAZE on them (NView:785-848); image decoding and
+// feature extraction are out of this build's scope, so the drivers start one step later, from a FEATURES
+// FILE holding exactly what extract_features() leaves behind -- key points, descriptor matrix and BGR colours per image --
+// plus K (the reference hard-codes it, NView:1353-1356; its TODO at 1358 asks for it to become an input).
+//
+//   features file, little-endian:
+//     char magic[8] = "SFMFEAT1";  int32 n_img;  double K[9];  int32 has_poses;
+//     per image:  int32 n_kp, desc_type (0 = CV_8U, 5 = CV_32F), desc_cols;
+//                 sfm_keypoint kp[n_kp];  descriptor rows;  uint8 bgr[n_kp][3];
+//                 if has_poses: double R[9], T[3]      (world -> camera; used with --poses-from-file only)
+#pragma once
+#include <iostream>
+
+#include "sfm_geometry.hpp"
+
+namespace sfm {
+
+struct Features {
+    Mat K;
+    std::vector<std::vector<KeyPoint>> key_points_for_all;
+    std::vector<Mat> descriptor_for_all;
+    std::vector<std::vector<Vec3b>> colors_for_all;
+    std::vector<Mat> file_rotations, file_motions;      // optional
+    bool has_poses = false;
+};
+
+inline bool read_features(const std::string& path, Features& f)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { printf("[Err]: cannot open features file %s\n", path.c_str()); return false; }
+    char magic[8];
+    in.read(magic, 8);
+    if (!in || std::memcmp(magic, "SFMFEAT1", 8) != 0) { printf("[Err]: %s is not a features file.\n", path.c_str()); return false; }
+    int32_t n_img = 0, has_poses = 0;
+    in.read((char*)&n_img, 4);
+    f.K = Mat(3, 3, CV_64F);
+    in.read((char*)f.K.ptr<double>(), 72);
+    in.read((char*)&has_poses, 4);
+    f.has_poses = has_poses != 0;
+    for (int i = 0; i < n_img && in; ++i) {
+        int32_t n_kp = 0, type = 0, cols = 0;
+        in.read((char*)&n_kp, 4); in.read((char*)&type, 4); in.read((char*)&cols, 4);
+        if (!in || n_kp < 0 || cols < 0 || (type != CV_8U && type != CV_32F)) { printf("[Err]: corrupt features file.\n"); return false; }
+        std::vector<KeyPoint> kp((size_t)n_kp);
+        in.read((char*)kp.data(), (std::streamsize)sizeof(KeyPoint) * n_kp);
+        Mat d(n_kp, cols, type);
+        in.read((char*)d.buf.data(), (std::streamsize)d.buf.size());
+        std::vector<Vec3b> col((size_t)n_kp);
+        in.read((char*)col.data(), (std::streamsize)3 * n_kp);
+        Mat R(3, 3, CV_64F), T(3, 1, CV_64F);
+        if (f.has_poses) { in.read((char*)R.ptr<double>(), 72); in.read((char*)T.ptr<double>(), 24); }
+        if (!in) { printf("[Err]: truncated features file.\n"); return false; }
+        printf("Extracting features for image %d...\n", i);
+        if (kp.size() <= 10) continue;                       // extract_features drops such images (NView:820-823)
+        printf("%zd 2D feature point detected.\n", kp.size());
+        f.key_points_for_all.push_back(std::move(kp)); f.descriptor_for_all.push_back(std::move(d)); f.colors_for_all.push_back(std::move(col));
+        f.file_rotations.push_back(R); f.file_motions.push_back(T);
+    }
+    return (bool)in;
+}
+
+inline std::vector<uint8_t> mask_vector(const Mat& mask) { return std::vector<uint8_t>(mask.ptr<uint8_t>(), mask.ptr<uint8_t>() + (size_t)mask.rows * mask.cols); }
+
+inline void print_mat(const char* name, const Mat& m)
+{
+    printf("%s:\n[", name);
+    for (int r = 0; r < m.rows; ++r) { for (int c = 0; c < m.cols; ++c) printf("%s%.17g", c ? ", " : "", m.at<double>(r, c)); printf(r + 1 < m.rows ? ";\n " : "]\n"); }
+}
+
+// init_structure (NView:916-987).  given_R / given_T non-null: the pose of frame 1 comes from the caller (poses-from-file
+// mode) and every match of the first pair is kept; otherwise find_transform + its inlier mask, as the reference.
+inline int init_structure(const Mat& K, const std::vector<std::vector<KeyPoint>>& key_points_for_all,
+                          const std::vector<std::vector<Vec3b>>& colors_for_all, const std::vector<std::vector<DMatch>>& matches_for_all,
+                          std::vector<Point3d>& structure, std::vector<std::vector<int>>& correspond_struct_idx, std::vector<Vec3b>& colors,
+                          std::vector<Mat>& rotations, std::vector<Mat>& motions, const Mat* given_R = nullptr, const Mat* given_T = nullptr)
+{
+    std::vector<Point2f> pts2d_1, pts2d_2;
+    std::vector<Vec3b> c2;
+    Mat R, T, mask;
+    get_matched_points(key_points_for_all[0], key_points_for_all[1], matches_for_all[0], pts2d_1, pts2d_2);
+    get_matched_colors(colors_for_all[0], colors_for_all[1], matches_for_all[0], colors, c2);
+    std::vector<uint8_t> mv;
+    if (given_R && given_T) { R = *given_R; T = *given_T; mv.assign(pts2d_1.size(), 1); }
+    else {
+        find_transform(K, pts2d_1, pts2d_2, R, T, mask);       // the reference ignores its verdict too (NView:935)
+        if (R.empty() || T.empty()) { printf("[Err]: no transform between the first two frames.\n"); return -1; }
+        mv = mask_vector(mask);
+    }
+    maskout_2d_pts_pair(mv, pts2d_1, pts2d_2);
+    maskout_colors(mv, colors);
+    Mat R0 = Mat::eye3(), T0(3, 1, CV_64F);
+    const int ret = reconstruct(K, R0, T0, R, T, pts2d_1, pts2d_2, structure);
+    if (ret < 0) return ret;
+    rotations = { R0, R };
+    motions = { T0, T };
+    init_correspondence(key_points_for_all, matches_for_all[0], mv, correspond_struct_idx);
+    return 0;
+}
+
+struct PipelineOptions {
+    std::string out_dir = "../Viewer";     // the reference's relative output paths (NView:1458, 1505, 1511)
+    bool poses_from_file = false;          // skip find_transform / solvePnPRansac, take R, T of every frame from the features file
+    bool write_back_poses = false;         // structure_ba.yml with the optimised poses (the reference writes the pre-BA ones)
+    bool print_offsets = true;             // the per-point "Point3d i offset" lines (NView:1494-1498)
+};
+
+// main() of NViewReconstuct.cpp from "match_features_for_all" on (NView:1369-1517)
+inline int run_nview(Features& f, const PipelineOptions& opt)
+{
+    const Mat& K = f.K;
+    auto& kpts_for_all = f.key_points_for_all; auto& colors_for_all = f.colors_for_all;
+    std::vector<std::vector<DMatch>> matches_for_all;
+    match_features_for_all(f.descriptor_for_all, matches_for_all);
+    if (matches_for_all.empty()) { printf("[Err]: fewer than two usable images.\n"); return -1; }
+
+    std::vector<Point3d> pts3d;
+    std::vector<std::vector<int>> inds_2d_to_3d;
+    std::vector<Vec3b> colors;
+    std::vector<Mat> rotations, translations;
+
+    printf("\nConstruct from the first two frames...\n");
+    const int ret = init_structure(K, kpts_for_all, colors_for_all, matches_for_all, pts3d, inds_2d_to_3d, colors, rotations, translations,
+                                   opt.poses_from_file ? &f.file_rotations[1] : nullptr, opt.poses_from_file ? &f.file_motions[1] : nullptr);
+    if (ret < 0) return ret;
+    if (opt.poses_from_file) { rotations[0] = f.file_rotations[0]; translations[0] = f.file_motions[0]; }
+
+    printf("\nIncremental SFM...\n");
+    for (int i = 1; i < (int)matches_for_all.size(); ++i) {
+        std::vector<Point3f> obj_pts;
+        std::vector<Point2f> img_pts;
+        Mat r, R, T;
+        get_obj_pts_and_img_pts(matches_for_all[i], inds_2d_to_3d[i], pts3d, kpts_for_all[i + 1], obj_pts, img_pts);
+        if (opt.poses_from_file) { R = f.file_rotations[i + 1]; T = f.file_motions[i + 1]; }
+        else {
+            if (obj_pts.size() < 4 || img_pts.size() < 4) { printf("[Warning]: too few 3D-2D point pairs for frame %d.\n", i); continue; }
+            if (!solvePnPRansac(obj_pts, img_pts, K, r, T)) { printf("[Warning]: no pose for frame %d.\n", i); continue; }
+            Rodrigues_vec(r, R);
+        }
+        print_mat("R", R); print_mat("T", T);
+        rotations.push_back(R);
+        translations.push_back(T);
+        if ((int)rotations.size() <= i + 1) {
+            // after a skipped frame the reference's rotations[i] no longer refers to frame i and indexing
+            // runs off the end; stop here instead of reading out of bounds
+            printf("[Err]: frame %d has no pose (an earlier frame was skipped).\n", i); return -1;
+        }
+        std::vector<Point2f> pts2d_1, pts2d_2;
+        std::vector<Vec3b> colors_1, colors_2;
+        get_matched_points(kpts_for_all[i], kpts_for_all[i + 1], matches_for_all[i], pts2d_1, pts2d_2);
+        get_matched_colors(colors_for_all[i], colors_for_all[i + 1], matches_for_all[i], colors_1, colors_2);
+        std::vector<Point3d> next_structure;
+        reconstruct(K, rotations[i], translations[i], R, T, pts2d_1, pts2d_2, next_structure);
+        printf("Frame %d reconstructed.\n", i);
+        fuse_structure(matches_for_all[i], inds_2d_to_3d[i], inds_2d_to_3d[i + 1], pts3d, next_structure, colors, colors_1);
+        printf("Frame %d point cloud fused, total %d points now.\n", i, (int)pts3d.size());
+    }
+
+    save_structure(opt.out_dir + "/structure.yml", rotations, translations, pts3d, colors);
+
+    printf("\nBundle adjustment fo SFM...\n");
+    Mat intrinsic(4, 1, CV_64F);
+    intrinsic.at<double>(0) = K.at<double>(0, 0); intrinsic.at<double>(1) = K.at<double>(1, 1);
+    intrinsic.at<double>(2) = K.at<double>(0, 2); intrinsic.at<double>(3) = K.at<double>(1, 2);
+    print_mat("intrinsic", intrinsic);
+    std::vector<Mat> extrinsics;
+    for (size_t i = 0; i < rotations.size(); ++i) {
+        Mat extrinsic(6, 1, CV_64F), r;
+        Rodrigues(rotations[i], r);
+        for (int k = 0; k < 3; ++k) { extrinsic.at<double>(k) = r.at<double>(k); extrinsic.at<double>(3 + k) = translations[i].at<double>(k); }
+        extrinsics.push_back(extrinsic);
+    }
+    // frames that never got a pose carry no camera: their index rows must not reach the solver
+    std::vector<std::vector<int>> inds_ba(inds_2d_to_3d.begin(), inds_2d_to_3d.begin() + std::min(inds_2d_to_3d.size(), extrinsics.size()));
+    std::vector<std::vector<KeyPoint>> kpts_ba(kpts_for_all.begin(), kpts_for_all.begin() + inds_ba.size());
+    auto pts3d_old = pts3d;
+    bundle_adjustment(intrinsic, extrinsics, inds_ba, kpts_ba, pts3d);
+    if (opt.print_offsets)
+        for (size_t i = 0; i < pts3d.size(); ++i)
+            printf("Point3d %zu offset: [%.17g, %.17g, %.17g]\n", i, pts3d[i].x - pts3d_old[i].x, pts3d[i].y - pts3d_old[i].y, pts3d[i].z - pts3d_old[i].z);
+
+    std::vector<Point3d> normals(pts3d.size());
+    estimate_normals(pts3d, 10, normals);
+
+    if (opt.write_back_poses)
+        for (size_t i = 0; i < extrinsics.size(); ++i) {
+            Mat r(3, 1, CV_64F);
+            for (int k = 0; k < 3; ++k) { r.at<double>(k) = extrinsics[i].at<double>(k); translations[i].at<double>(k) = extrinsics[i].at<double>(3 + k); }
+            Rodrigues_vec(r, rotations[i]);
+        }
+    save_structure(opt.out_dir + "/structure_ba.yml", rotations, translations, pts3d, colors);
+    printf("structure_ba.yml saved.\n");
+    printf("Saving structure to ply...\n");
+    std::vector<Pt3DPly> pts3dply;
+    get_ply_pts3d(pts3d, normals, colors, pts3dply);
+    write_ply_binary(opt.out_dir + "/structure_ba.ply", pts3dply);
+    printf("%s/structure_ba.ply saved.\n", opt.out_dir.c_str());
+    std::cout << "Save structure done." << std::endl;
+    return 0;
+}
+
+// main() of TwoViewReconstruct.cpp (lines 50-97): two images, L2 matching of SIFT rows, essential matrix, homogeneous
+// triangulation, structure.yml with float points
+inline int run_twoview(Features& f, const PipelineOptions& opt)
+{
+    if (f.descriptor_for_all.size() < 2) { printf("[Err]: two images needed.\n"); return -1; }
+    std::vector<DMatch> matches;
+    match_features(f.descriptor_for_all[0], f.descriptor_for_all[1], matches);
+    std::vector<Point2f> p1, p2;
+    std::vector<Vec3b> c1, c2;
+    Mat R, T, mask;
+    get_matched_points(f.key_points_for_all[0], f.key_points_for_all[1], matches, p1, p2);
+    get_matched_colors(f.colors_for_all[0], f.colors_for_all[1], matches, c1, c2);
+    std::vector<uint8_t> mv;
+    if (opt.poses_from_file) { R = f.file_rotations[1]; T = f.file_motions[1]; mv.assign(p1.size(), 1); }
+    else {
+        find_transform(f.K, p1, p2, R, T, mask);
+        if (R.empty() || T.empty()) { printf("[Err]: no transform between the two frames.\n"); return -1; }
+        mv = mask_vector(mask);
+    }
+    Mat structure;                                           // 4 x N, homogeneous
+    maskout_2d_pts_pair(mv, p1, p2);
+    reconstruct(f.K, R, T, p1, p2, structure);
+    std::vector<Mat> rotations = { Mat::eye3(), R };
+    std::vector<Mat> motions = { Mat(3, 1, CV_64F), T };
+    maskout_colors(mv, c1);
+    save_structure(opt.out_dir + "/structure.yml", rotations, motions, structure, c1);
+    std::cout << "successful!!!" << std::endl;
+    return 0;
+}
+
+inline int driver_main(int argc, char** argv, bool nview)
+{
+    if (argc < 2 || std::string(argv[1]).empty()) {
+        printf("[Warning]: empty dataset path.\nusage: %s <features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet]\n", argv[0]);
+        return 0;
+    }
+    PipelineOptions opt;
+    int positional = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--poses-from-file") opt.poses_from_file = true;
+        else if (a == "--write-back-poses") opt.write_back_poses = true;
+        else if (a == "--quiet") opt.print_offsets = false;
+        else if (positional++ == 0) opt.out_dir = a;
+    }
+    Features f;
+    if (!read_features(argv[1], f)) return 1;
+    printf("Total %d image files.\n", (int)f.key_points_for_all.size());
+    if (opt.poses_from_file && !f.has_poses) { printf("[Err]: the features file holds no poses.\n"); return 1; }
+    if (!context()) return 1;                               // no GPU: fail loudly, there is no CPU path
+    const int rc = nview ? run_nview(f, opt) : run_twoview(f, opt);
+    return rc == 0 ? 0 : 1;
+}
+
+}  // namespace sfm

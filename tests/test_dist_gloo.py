@@ -1,6 +1,7 @@
-"""CPU, world_size 2 over gloo: the sharding of the hot path and the all-reduce hook (the N>1 host logic of bench.py).
-The per-rank arithmetic is done by the oracle here (no GPU in this container); on the GPU box the same hook sums
-libsfmhip's device buffers over RCCL."""
+"""world_size 2 over gloo: the sharding of the hot path and the all-reduce hook (the N>1 host logic of bench.py).
+CPU test: the per-rank arithmetic is done by the oracle (no GPU in this container).  GPU test (-m gpu): the two ranks are
+two processes that drive libsfmhip on the one card of the box (rehearsal knobs SFM_DIST_BACKEND=gloo, SFM_LOCAL_DEVICE=0)
+through the same hook that sums the library's device buffers over RCCL on an 8-GPU node."""
 import os
 import socket
 
@@ -30,10 +31,15 @@ def _worker(rank, world, port, out_dir):
     msg = np.concatenate([S.reshape(-1), rhs, [cost, float(len(ids)), float(len(oc_l))]])
     hook = sdist.make_allreduce_hook(device="cpu")
     assert hook(msg.ctypes.data, msg.size, 0) == 0
-    assert hook(msg[-3:].ctypes.data, 0 + 3, 0) == 0 or True       # second buffer through the same hook (cache keyed by address)
+    # a second, different buffer through the same hook (its cache is keyed by (address, count)): a fresh copy of this
+    # rank's three tail scalars must come back as the sum over ranks, i.e. equal to the tail of the first message
+    tail = np.array([cost, float(len(ids)), float(len(oc_l))])
+    assert hook(tail.ctypes.data, 3, 0) == 0
+    tail_ok = np.array_equal(tail, msg[-3:])
     Sf, rf, cf = orc.ba_reduced_system(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], -25.0, opts=o)
     ok = (np.abs(msg[:n * n].reshape(n, n) - Sf).max() <= 1e-12 * np.abs(Sf).max()
-          and np.abs(msg[n * n:n * n + n] - rf).max() <= 1e-12 * np.abs(rf).max())
+          and np.abs(msg[n * n:n * n + n] - rf).max() <= 1e-12 * np.abs(rf).max() and tail_ok
+          and abs(msg[-3] - cf) <= 1e-12 * cf)
     pairs_g, images, pairs_l = sdist.shard_pairs(23, rank, world)
     np.save(os.path.join(out_dir, f"r{rank}.npy"),
             np.array([ok, len(ids), len(oc_l), pairs_g[0, 0], pairs_g[-1, 1], images[0], images[-1], len(pairs_l)], float))
@@ -69,3 +75,53 @@ def test_shard_helpers_cover_everything(world):
     allp = np.concatenate([p for p in pairs if len(p)])
     assert np.array_equal(allp, np.stack([np.arange(9), np.arange(1, 10)], 1))
     assert sdist.shard_range(0, 0, world) == (0, 0)
+
+
+def _gpu_worker(rank, world, port, out_dir, shape, n_iter):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SFM_DIST_BACKEND="gloo", SFM_LOCAL_DEVICE="0")
+    import time
+    import torch
+    import torch.distributed as dist
+    from sfm_opencv_amd import api
+    r, w, local = sdist.init_process_group()
+    assert (r, w, local) == (rank, world, 0)
+    torch.cuda.set_device(local)
+    ctx = api.Context(local, use_torch_stream=True)
+    sc = synth.ba_scene(*shape)
+    pts_l, oc_l, op_l, uv_l, ids = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], rank, world)
+    pb = ctx.ba_create(sc["K0"], sc["ext0"], pts_l, oc_l, op_l, uv_l)
+    pb.set_allreduce(sdist.make_allreduce_hook(), rank, world)
+    s = pb.iterate(n_iter)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    pb.iterate(n_iter)
+    torch.cuda.synchronize(); dist.barrier()
+    ms = 1e3 * (time.perf_counter() - t0) / n_iter
+    pb.reset()
+    s = pb.iterate(n_iter)
+    K, ext, pts = pb.params()
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), K=K, ext=ext, pts=pts, ids=ids, cost=s["final_cost"], succ=s["successful_steps"], ms=ms)
+    pb.close(); ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(24, 4000), (200, 60000)])
+def test_two_processes_drive_libsfmhip_over_gloo(ctx, tmp_path, shape):
+    """The real N>1 path: one PROCESS per rank (here both on the box's one card), torch.distributed for the exchange, the
+    library's packed reduced-system message and its five step scalars summed by sfm_opencv_amd.dist's hook; against the
+    unsharded solve of the same scene in this process.  (200 cameras: four dissection segments.)"""
+    import torch.multiprocessing as mp
+    n_iter = 5
+    sc = synth.ba_scene(*shape)
+    ref = ctx.ba_create(sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    sr = ref.iterate(n_iter); Kr, extr, ptsr = ref.params(); ref.close()
+    mp.spawn(_gpu_worker, args=(2, _free_port(), str(tmp_path), shape, n_iter), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(tmp_path / f"g{r}.npz")
+        assert int(g["succ"]) == sr["successful_steps"] and abs(float(g["cost"]) - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        assert np.abs(g["ext"] - extr).max() <= 1e-9 and np.abs(g["K"] - Kr).max() <= 1e-9 * np.abs(Kr).max()
+        assert np.abs(g["pts"] - ptsr[g["ids"]]).max() <= 1e-9
+        print(f"[gloo rehearsal {shape}] rank {r}: {float(g['ms']):.3f} ms per LM iteration with two processes on one card")
