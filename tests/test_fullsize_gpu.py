@@ -199,8 +199,12 @@ def test_c5_pair_knn_oracle_slice(ctx):
     perm = np.random.default_rng(13).permutation(10000)
     gi2, gd2 = ctx.knn2_l2(a, b[perm])
     assert np.array_equal(gd.view(np.uint32), gd2.view(np.uint32))
-    clean = gd[:, 0] != gd[:, 1]
-    assert np.array_equal(perm[gi2[clean]], gi[clean])
+    clean = gd[:, 0] != gd[:, 1]                          # (the runner-up may still tie with the third: its index is checked by distance)
+    assert np.array_equal(perm[gi2[clean, 0]], gi[clean, 0])
+    same = perm[gi2[:, 1]] == gi[:, 1]
+    assert same.mean() > 0.99
+    for i in np.nonzero(~same)[0]:
+        assert np.sqrt(((a[i] - b[perm[gi2[i, 1]]]) ** 2).sum(dtype=np.float64)) == np.sqrt(((a[i] - b[gi[i, 1]]) ** 2).sum(dtype=np.float64))
 
 
 @pytest.fixture(scope="module")
