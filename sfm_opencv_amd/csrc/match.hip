@@ -380,8 +380,17 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     float* stage_out = (float*)(lds + 2 * 128 * DP + 2 * 128 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int t_begin = blockIdx.y * blocks_per_wg * 128;
+    // XCD-banded work mapping (speed only): workgroups are dealt round-robin to the 8 XCDs, so workgroup L works on the
+    // band of query blocks qb = 8 (slot / n_tb) + L % 8 and walks along it (tb = slot % n_tb, slot = L / 8): horizontally
+    // adjacent tiles -- which share the 128-B lines straddling their common edge whenever the row stride is not a
+    // multiple of 32 floats (the reference's dense 10000-column cv::Mat) -- pass through ONE L2 one after the other and
+    // leave it as whole lines.  Pure-writer check (experiments/wbw4.hip): 103 -> 88 us at stride 10000, 82 -> 76 us aligned.
+    const int n_qb = (nq + 127) >> 7, n_tb = (nt_pad / 128 + blocks_per_wg - 1) / blocks_per_wg;
+    const int L = blockIdx.x, slot = L >> 3;
+    const int qb = (slot / n_tb) * 8 + (L & 7), tb = slot % n_tb;
+    if (qb >= n_qb) return;
+    const int q0 = qb * 128 + wave * 32;
+    const int t_begin = tb * blocks_per_wg * 128;
     int nblocks = (nt_pad - t_begin) / 128; if (nblocks > blocks_per_wg) nblocks = blocks_per_wg;
     if (nblocks <= 0) return;
 
@@ -1265,7 +1274,8 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
         if (const char* em = getenv("SFMHIP_EXP_DISTMAT")) exp_mode = atoi(em);
         if (const char* eb = getenv("SFMHIP_EXP_BPW")) bpw = atoi(eb);
 #endif
-        const dim3 grid(query->rows_pad / 128, ceil_div(train->rows_pad / 128, bpw));
+        const int n_qb = ceil_div(query->rows, 128), n_tb = ceil_div(train->rows_pad / 128, bpw);
+        const dim3 grid((unsigned)(8 * ceil_div(n_qb, 8) * n_tb));     // decoded in the kernel (XCD-banded mapping)
         const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
         const int ks = query->dim_pad / 32;
 #define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
