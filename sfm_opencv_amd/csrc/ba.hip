@@ -416,9 +416,18 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     hipStream_t st = ctx->stream;
     BADev P = make_dev(h, radius);
     hipLaunchKernelGGL(ba_camstep_kernel, dim3(1 + ceil_div(h->nc, 256)), dim3(256), 0, st, P, h->d_cam2);     // block 0: the step; the others: candidate rotation blocks
-    hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P);
-    // single rank: the reduction also publishes the decision scalars (ba_loop then skips ba_publish_kernel)
+    // single rank: the reduction also publishes the decision scalars (ba_loop then skips ba_publish_kernel), and extra
+    // workgroups of the back-substitution zero-fill S and the solver's private buffers for the next linearisation.  (The tail
+    // [rhs | diagU | graw | scalars] needs no refill there: the finalisation stores every real entry and the padding
+    // entries stay zero through the solve; on several ranks the other ranks' slots must be cleared, so the build memsets.)
     const bool fuse_publish = !h->ar_fn && h->publish_in_back;
+    size_t n0 = 0, n1 = 0;
+    if (fuse_publish) {
+        n0 = (size_t)h->npad * h->npad;
+        if (h->use_sparse && h->nseg > 1 && h->d_topbuf) { n1 = h->topbuf_count & ~(size_t)1; h->top_cleared = (n1 == h->topbuf_count); }
+        h->cleared = true;
+    }
+    hipLaunchKernelGGL(ba_back_kernel, dim3(h->n_pt_blocks + (n0 + n1 ? BACK_ZERO_BLOCKS : 0)), dim3(256), 0, st, P, h->n_pt_blocks, h->d_msg, n0, h->d_topbuf, n1);
     const double* d_scal = h->d_msg + (size_t)h->npad * h->npad + 3 * (size_t)h->npad;
     hipLaunchKernelGGL(ba_back_reduce_kernel, dim3(1), dim3(256), 0, st, h->d_part_back, h->n_pt_blocks, h->d_back4,
                        d_scal, h->d_cam2, h->d_err, fuse_publish ? h->h_scal : (double*)nullptr, fuse_publish ? ++h->pub_seq : 0ull);
@@ -671,11 +680,6 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
             hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
         }
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
-        if (!h->ar_fn) {
-            SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_msg, 0, h->msg_count * sizeof(double), st));
-            h->cleared = true;
-            if (h->use_sparse && h->nseg > 1 && h->d_topbuf) { SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st)); h->top_cleared = true; }
-        }
         // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
         // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
         bool speculated = false;

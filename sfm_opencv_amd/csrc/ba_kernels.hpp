@@ -983,10 +983,24 @@ __device__ __forceinline__ double back_rec_value(const BADev& P, int c, int f)
     return 0.0;
 }
 
-__global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P)
+// Workgroups beyond n_pt_blocks zero-fill [z0, z0 + n0) and [z1, z1 + n1) (16-byte aligned, counts even): on a single
+// rank the reduced system S and the solver's private buffers, which the factorisation has consumed by now and the next
+// linearisation expects empty -- as two hipMemsetAsync calls behind the step's last kernel they sat on the critical path.
+#define BACK_ZERO_BLOCKS 512
+__global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P, int n_pt_blocks, double* __restrict__ z0, size_t n0, double* __restrict__ z1, size_t n1)
 {
     __shared__ double red[4][4];
     __shared__ __attribute__((aligned(16))) double cam[BACK_NCL][BACK_REC];
+    if ((int)blockIdx.x >= n_pt_blocks) {
+        const size_t zb = blockIdx.x - n_pt_blocks, nzb = gridDim.x - n_pt_blocks;
+        const size_t total2 = (n0 + n1) / 2, per = (total2 + nzb - 1) / nzb, h0 = n0 / 2;
+        const size_t e_end = (zb + 1) * per < total2 ? (zb + 1) * per : total2;
+        const double2 zz = make_double2(0.0, 0.0);
+        for (size_t e = zb * per + threadIdx.x; e < e_end; e += 256) {
+            if (e < h0) ((double2*)z0)[e] = zz; else ((double2*)z1)[e - h0] = zz;
+        }
+        return;
+    }
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[4] = { 0, 0, 0, 0 };
