@@ -176,11 +176,14 @@ struct sfmhip_ba {
     int *d_prow_start = nullptr, *d_prow = nullptr; bool use_sparse = false; int max_panel_rows = 0;
     std::vector<int> host_blk_cam;
     // layout of the reduced system (nested-dissection ordering of the camera chain, segments padded to 32-blocks)
-    int npad_max = 0, nseg = 1, top_blk = 0; long long nnz_blocks = 0;
+    int npad_max = 0, nseg = 1, top_blk = 0, solver_pmax = 1; long long nnz_blocks = 0;      // nseg: leaves of the dissection (1: none)
     std::vector<int> cam_pos, pos_param;      // camera -> first position (-1 constant); position -> natural index (-1 pad)
     std::vector<int> pt_slot;                 // caller's point index -> slot in the HBM arrays (points sorted by camera set)
-    int *d_cam_pos = nullptr, *d_posmask = nullptr, *d_seg_blk = nullptr;
-    double* d_topbuf = nullptr; size_t topbuf_count = 0;
+    int *d_cam_pos = nullptr, *d_posmask = nullptr;
+    double* d_topbuf = nullptr; size_t topbuf_count = 0, topbuf_cap = 0;      // the nodes' private update buffers (zero on entry to the solve)
+    // elimination tree of the dissection: nodes in elimination order, level l = nodes [lvl_first[l], lvl_first[l + 1]), then the top node
+    NodeDesc* d_nodes = nullptr; size_t nodes_cap = 0; FoldEnt* d_ents = nullptr; size_t ents_cap = 0;
+    std::vector<int> lvl_first; int top_node = 0;
     int* d_sblk = nullptr; int n_sblk = 0; size_t sblk_cap = 0; double* d_pack = nullptr; size_t pack_cap = 0;     // packed all-reduce message
     double *d_ouv = nullptr, *d_cam_uv = nullptr;
     // work
@@ -387,11 +390,16 @@ static int enqueue_solve(sfmhip_ba* h)
         } else {
             if (!h->top_cleared) SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_topbuf, 0, h->topbuf_count * sizeof(double), st));
             h->top_cleared = false;
-            if (ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][3], st);
-            hipLaunchKernelGGL(chol_nd_forward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_topbuf, h->d_err);
-            if (ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][4], st);
-            hipLaunchKernelGGL(chol_nd_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->nseg, rhs_rw, h->d_topbuf, h->d_y, h->d_err);
-            hipLaunchKernelGGL(chol_nd_backward_kernel, dim3(h->nseg), dim3(STHREADS), 0, st, S, ld, pl, h->d_seg_blk, rhs_rw, h->d_y);
+            const int nlev = (int)h->lvl_first.size() - 1;
+            for (int l = 0; l < nlev; ++l) {        // one launch per level, a workgroup per node
+                if (l == 0 && ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][3], st);
+                hipLaunchKernelGGL(chol_node_forward_kernel, dim3(h->lvl_first[l + 1] - h->lvl_first[l]), dim3(STHREADS), 0, st, S, ld, pl, h->d_nodes, h->lvl_first[l],
+                                   rhs_rw, h->d_topbuf, h->d_ents, h->d_err);
+                if (l == 0 && ctx->timing) (void)hipEventRecord(h->evi[h->iter_parity][4], st);
+            }
+            hipLaunchKernelGGL(chol_top_kernel, dim3(1), dim3(STHREADS), 0, st, S, ld, pl, h->d_nodes, h->top_node, rhs_rw, h->d_ents, h->d_y, h->d_err);
+            for (int l = nlev - 1; l >= 0; --l)
+                hipLaunchKernelGGL(chol_node_backward_kernel, dim3(h->lvl_first[l + 1] - h->lvl_first[l]), dim3(STHREADS), 0, st, S, ld, pl, h->d_nodes, h->lvl_first[l], rhs_rw, h->d_y);
         }
         SFM_HIP_TRY(ctx, hipGetLastError());
         return SFMHIP_OK;
@@ -438,12 +446,24 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     return call_allreduce(h, h->d_back4, 5);
 }
 
-// Layout + block fill pattern of the reduced system -> per-panel row lists for the solver kernels.
+// Layout + block fill pattern of the reduced system -> per-panel row lists and the elimination tree for the solver kernels.
 //  1. camera adjacency (cameras sharing a point); multi-rank: union over ranks through the all-reduce hook.
 //  2. ordering: if the camera graph is a narrow band (the reference's tracks only chain through consecutive frames),
-//     cut the chain into `nseg` segments separated by `w` cameras; order [segment interiors (each padded to whole
-//     32-blocks) | separators | intrinsics].  Segment interiors are mutually independent => one workgroup each.
-//  3. symbolic block factorisation in that order -> rows(k); verify the independence, else fall back to one segment.
+//     multi-level nested dissection of the chain (ba_solver.hpp): P = 2^m leaf segments separated by `w` cameras,
+//     Lp levels of mutually independent separators, then a serially factored top (remaining separators + intrinsics).
+//     Every parallel node is padded to whole 32-blocks.
+//  3. symbolic block factorisation in that order -> rows(k); every node's panels may only reach its own range and blocks
+//     of LATER levels (at most SAMAX of them, SRMAX per panel), else the next simpler configuration is tried, down to a
+//     single node (chol_sparse_kernel) and finally the dense blocked fallback.
+static int solver_pick_leaves(int ncf, int w)
+{
+    // leaves of at least max(3 w, 16) cameras (three panels' worth: every level costs a launch and a handful of dependent
+    // round trips to buffers other workgroups wrote, ~25 us at C4 -- measured, profiles/README.md), at most 64 of them
+    int P = 1;
+    while (P < 64 && w >= 1 && (ncf - (2 * P - 1) * w) / (2 * P) >= std::max(3 * w, 16)) P *= 2;
+    return P;
+}
+
 static int build_solver_plan(sfmhip_ba* h)
 {
     sfmhip_ctx* ctx = h->ctx;
@@ -464,43 +484,81 @@ static int build_solver_plan(sfmhip_ba* h)
     int w = 0;
     for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c) if (adj[(size_t)a * ncf + c] != 0.0) w = std::max(w, a - c);
 
-    int want = 4;
+    // candidate configurations (leaves, parallel separator levels), best first
+    struct Cfg { int P, Lp; };
+    std::vector<Cfg> cfgs;
+    {
+        int P0 = std::min(solver_pick_leaves(ncf, w), h->solver_pmax), Lp0 = -1;
 #ifdef SFMHIP_EXPERIMENTS
-    if (const char* e = getenv("SFMHIP_ND_SEGMENTS")) want = std::min(SRMAX, std::max(1, atoi(e)));     // chol_nd_top_kernel folds at most SRMAX private buffers
+        if (const char* e = getenv("SFMHIP_ND_LEAVES")) { int v = std::max(1, atoi(e)); P0 = 1; while (P0 * 2 <= v && P0 * 2 <= h->solver_pmax) P0 *= 2; }
+        if (const char* e = getenv("SFMHIP_ND_LEVELS")) Lp0 = std::max(0, atoi(e));
 #endif
-    static_assert(SRMAX + 1 <= 16, "d_seg_blk holds 16 entries");
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        // ---- 2. ordering
-        int P = attempt == 0 ? want : 1;
-        while (P > 1 && (w < 1 || (ncf - (P - 1) * w) / P < 3 * w + 6)) P /= 2;
-        if (P < 1) P = 1;
-        std::vector<int> is_sep((size_t)std::max(ncf, 1), 0), seg_of((size_t)std::max(ncf, 1), 0);
+        for (int P = P0; P >= 2; P /= 2) {
+            int m = 0; while ((1 << m) < P) ++m;
+            // by default every separator level but the last two is parallel (the top keeps <= 3 separators + the intrinsics)
+            int Lp = Lp0 >= 0 ? std::min(Lp0, m) : std::max(0, m - 2);
+            cfgs.push_back({ P, Lp });
+            if (Lp > 0 && Lp0 < 0) cfgs.push_back({ P, 0 });
+        }
+        cfgs.push_back({ 1, 0 });
+    }
+    for (const Cfg cfg : cfgs) {
+        const int P = cfg.P, Lp = cfg.Lp;
+        if (P > 1 && (w < 1 || (ncf - (P - 1) * w) / P < 1)) continue;
+        // ---- 2. ordering.  chain = leaf 0 | sep 0 | leaf 1 | sep 1 | ... | leaf P-1; level of sep i = ctz(i + 1) + 1
+        std::vector<int> node_of((size_t)std::max(ncf, 1), 0);       // chain camera -> node index (elimination order); -1: top
+        std::vector<int> node_level;                                  // per parallel node
+        int n_par = 0;
+        std::vector<int> first_of_level(1, 0);
         if (P > 1) {
             const int interior = ncf - (P - 1) * w;
+            std::vector<int> leaf_lo(P), leaf_hi(P), sep_lo(std::max(P - 1, 1));
             int pos = 0;
-            for (int sgi = 0; sgi < P; ++sgi) {
-                const int len = interior / P + (sgi < interior % P ? 1 : 0);
-                for (int k = 0; k < len; ++k) seg_of[pos++] = sgi;
-                if (sgi + 1 < P) for (int k = 0; k < w; ++k) { is_sep[pos] = 1; seg_of[pos++] = sgi; }
+            for (int j = 0; j < P; ++j) {
+                const int len = interior / P + (j < interior % P ? 1 : 0);
+                leaf_lo[j] = pos; pos += len; leaf_hi[j] = pos;
+                if (j + 1 < P) { sep_lo[j] = pos; pos += w; }
             }
+            for (int j = 0; j < P; ++j) { for (int i = leaf_lo[j]; i < leaf_hi[j]; ++i) node_of[i] = n_par; node_level.push_back(0); ++n_par; }
+            first_of_level.push_back(n_par);
+            for (int L = 1; L <= Lp; ++L) {
+                for (int i = 0; i + 1 < P; ++i)
+                    if (__builtin_ctz(i + 1) + 1 == L) { for (int k = 0; k < w; ++k) node_of[sep_lo[i] + k] = n_par; node_level.push_back(L); ++n_par; }
+                first_of_level.push_back(n_par);
+            }
+            // the top: remaining separators by (level, index); their cameras get increasing "top ranks" for the ordering below
+            int rank = 0;
+            for (int L = Lp + 1; L <= 31; ++L)
+                for (int i = 0; i + 1 < P; ++i)
+                    if (__builtin_ctz(i + 1) + 1 == L) { for (int k = 0; k < w; ++k) node_of[sep_lo[i] + k] = -1 - (rank++); }
         }
+        // positions
         h->cam_pos.assign((size_t)nc, -1);
-        std::vector<int> seg_blk(P + 1, 0);
+        std::vector<int> node_k0, node_k1;
         int pos = 0;
-        for (int sgi = 0; sgi < P; ++sgi) {
-            seg_blk[sgi] = pos / NB;
-            for (int i = 0; i < ncf; ++i) if (!is_sep[i] && seg_of[i] == sgi) { h->cam_pos[i + f0] = pos; pos += 6; }
-            if (P > 1) pos = round_up(pos, NB);
+        if (P > 1) {
+            for (int nd = 0; nd < n_par; ++nd) {
+                node_k0.push_back(pos / NB);
+                for (int i = 0; i < ncf; ++i) if (node_of[i] == nd) { h->cam_pos[i + f0] = pos; pos += 6; }
+                pos = round_up(pos, NB);
+                node_k1.push_back(pos / NB);
+            }
+            const int top_start = pos;
+            std::vector<std::pair<int, int>> tops;
+            for (int i = 0; i < ncf; ++i) if (node_of[i] < 0) tops.push_back({ -1 - node_of[i], i });
+            std::sort(tops.begin(), tops.end());
+            for (auto& t : tops) { h->cam_pos[t.second + f0] = pos; pos += 6; }
+            h->top_blk = top_start / NB;
+        } else {
+            for (int i = 0; i < ncf; ++i) { h->cam_pos[i + f0] = pos; pos += 6; }
         }
-        seg_blk[P] = pos / NB;
-        const int top_start = pos;
-        for (int i = 0; i < ncf; ++i) if (is_sep[i]) { h->cam_pos[i + f0] = pos; pos += 6; }
         h->koff = pos;
         if (!h->fixK) pos += 4;
         const int npad = std::max(NB, round_up(pos, NB));
         if (npad > h->npad_max) { if (P == 1) { ctx->last_error = "internal: npad_max"; return SFMHIP_E_ARG; } continue; }
         const int nb = npad / NB;
-        h->npad = npad; h->nbk = nb; h->nseg = P; h->top_blk = P > 1 ? top_start / NB : nb;
+        h->npad = npad; h->nbk = nb; h->nseg = P;
+        if (P == 1) h->top_blk = nb;
         h->pos_param.assign((size_t)npad, -1);
         for (int c = f0; c < nc; ++c) for (int j = 0; j < 6; ++j) h->pos_param[h->cam_pos[c] + j] = 6 * (c - f0) + j;
         if (!h->fixK) for (int j = 0; j < 4; ++j) h->pos_param[h->koff + j] = 6 * ncf + j;
@@ -521,42 +579,143 @@ static int build_solver_plan(sfmhip_ba* h)
             if (adj[(size_t)a * ncf + c] != 0.0) mark(h->cam_pos[a + f0], h->cam_pos[c + f0], 6, 6);
         std::vector<int> sblk;                      // blocks S can populate (before fill): what a multi-rank all-reduce carries
         for (int i = 0; i < nb; ++i) for (int j = 0; j <= i; ++j) if (Pm[(size_t)i * nb + j]) { sblk.push_back(i); sblk.push_back(j); }
+        std::vector<int> blk_node((size_t)nb, n_par);               // block -> node (n_par = the top)
+        for (int nd = 0; nd < n_par; ++nd) for (int k = node_k0[nd]; k < node_k1[nd]; ++k) blk_node[k] = nd;
         std::vector<int> start(nb + 1, 0), rows;
-        int maxR = 0; bool independent = true;
+        std::vector<std::vector<int>> anc((size_t)n_par);
+        int maxR = 0; bool valid = true;
         for (int k = 0; k < nb; ++k) {
             std::vector<int> rk;
             for (int i = k + 1; i < nb; ++i) if (Pm[(size_t)i * nb + k]) rk.push_back(i);
             for (size_t a = 0; a < rk.size(); ++a) for (size_t b = 0; b <= a; ++b) Pm[(size_t)rk[a] * nb + rk[b]] = 1;
             maxR = std::max(maxR, (int)rk.size());
-            if (P > 1 && k < h->top_blk) {
-                int sgi = 0; while (sgi + 1 < P && k >= seg_blk[sgi + 1]) ++sgi;
-                for (int i : rk) if (i < h->top_blk && !(i >= seg_blk[sgi] && i < seg_blk[sgi + 1])) independent = false;
-            }
+            const int nd = blk_node[k];
+            if (nd < n_par)
+                for (int i : rk) {
+                    const int ni = blk_node[i];
+                    if (ni == nd) continue;
+                    if (ni < n_par && node_level[ni] <= node_level[nd]) valid = false;      // reaches a sibling: not independent
+                    if (std::find(anc[nd].begin(), anc[nd].end(), i) == anc[nd].end()) anc[nd].push_back(i);
+                }
             rows.insert(rows.end(), rk.begin(), rk.end());
             start[k + 1] = (int)rows.size();
         }
-        if (P > 1 && (!independent || maxR > SRMAX)) continue;       // retry with a single segment
+        for (auto& a : anc) { std::sort(a.begin(), a.end()); if ((int)a.size() > SAMAX) valid = false; }
+        if (P > 1 && (!valid || maxR > SRMAX)) continue;       // next simpler configuration
         h->max_panel_rows = maxR;
         h->nnz_blocks = (long long)rows.size() + nb;
         h->use_sparse = maxR <= SRMAX && npad <= (SRMAX * SNB + 1) * SLD;
         if (h->force_dense) h->use_sparse = false;
+        if (!h->use_sparse && P > 1) continue;                  // the dense path uses the natural single-node layout
+        // ---- elimination tree tables
+        std::vector<NodeDesc> nodes((size_t)n_par + 1);
+        std::vector<FoldEnt> ents;
+        size_t u_total = 0;
+        if (P > 1) {
+            for (int nd = 0; nd < n_par; ++nd) {
+                NodeDesc& N = nodes[nd];
+                memset(&N, 0, sizeof N);
+                N.k0 = node_k0[nd]; N.k1 = node_k1[nd]; N.na = (int)anc[nd].size();
+                for (int a = 0; a < SAMAX; ++a) N.anc[a] = a < N.na ? anc[nd][a] : 0x7fffffff;
+                N.u_off = (long long)u_total;
+                const size_t ldu = (size_t)N.na * NB;
+                u_total += ldu * ldu + ldu;
+                u_total = (u_total + 1) & ~(size_t)1;
+            }
+            NodeDesc& T = nodes[n_par];
+            memset(&T, 0, sizeof T);
+            T.k0 = h->top_blk; T.k1 = nb; T.na = 0;
+            for (int a = 0; a < SAMAX; ++a) T.anc[a] = 0x7fffffff;
+            if (u_total > h->topbuf_cap) { int rc = dalloc(h, &h->d_topbuf, u_total); if (rc) return rc; h->topbuf_cap = u_total; }      // addresses go into the entries
+            double* const Sd = h->d_msg; double* const rhsd = h->d_msg + (size_t)npad * npad; double* const Ud = h->d_topbuf;
+            auto slot_of = [&](int node, int blk) { const auto& a = anc[node]; return (int)(std::find(a.begin(), a.end(), blk) - a.begin()); };
+            // assembly lists (extend-add): the parent of a node owns its lowest outside block
+            for (int cons = 0; cons <= n_par && valid; ++cons) {
+                NodeDesc& C = nodes[cons];
+                struct Src { long long key; int node, a, b; };        // key orders destinations; sources of one destination by node index
+                std::vector<Src> blocks, rhss;
+                const long long BIG = 1ll << 40;
+                for (int nd = 0; nd < n_par; ++nd) {
+                    if (nd == cons || anc[nd].empty() || blk_node[anc[nd][0]] != cons) continue;       // not a child
+                    for (int a = 0; a < (int)anc[nd].size(); ++a) {
+                        const int bi = anc[nd][a];
+                        if (blk_node[bi] == cons) rhss.push_back({ (long long)bi, nd, a, 0 });
+                        else {
+                            const int sa = cons < n_par ? slot_of(cons, bi) : -1;
+                            if (sa < 0 || sa >= (int)anc[cons].size()) { valid = false; break; }
+                            rhss.push_back({ BIG + sa, nd, a, 0 });
+                        }
+                        for (int b = 0; b <= a; ++b) {
+                            const int bj = anc[nd][b];
+                            if (blk_node[bj] == cons) blocks.push_back({ (long long)bi * nb + bj, nd, a, b });
+                            else {
+                                const int sa = slot_of(cons, bi), sb = slot_of(cons, bj);
+                                if (cons == n_par || sa >= (int)anc[cons].size() || sb >= (int)anc[cons].size()) { valid = false; break; }
+                                blocks.push_back({ BIG + (long long)sa * SAMAX + sb, nd, a, b });
+                            }
+                        }
+                    }
+                }
+                if (!valid) break;
+                // every diagonal block of its own columns is a destination (damping), with or without sources; a node without
+                // children (a leaf) has no list at all and damps its rows directly
+                if (!blocks.empty() || !rhss.empty() || cons == n_par)
+                    for (int k = C.k0; k < C.k1; ++k) blocks.push_back({ (long long)k * nb + k, -1, 0, 0 });
+                auto cmp = [](const Src& x, const Src& y) { return x.key != y.key ? x.key < y.key : x.node < y.node; };
+                std::sort(blocks.begin(), blocks.end(), cmp); std::sort(rhss.begin(), rhss.end(), cmp);
+                const long long ldc = (long long)C.na * NB;
+                auto emit = [&](const std::vector<Src>& v, bool is_rhs) {
+                    for (size_t i = 0; i < v.size();) {
+                        size_t j = i;
+                        FoldEnt E; memset(&E, 0, sizeof E);
+                        E.diag0 = -1;
+                        const long long key = v[i].key;
+                        if (key >= BIG) {                       // hand-on into this node's own update buffer
+                            const long long q = key - BIG;
+                            if (is_rhs) { E.dst = Ud + C.u_off + ldc * ldc + q * NB; E.dst_ld = 0; }
+                            else { E.dst = Ud + C.u_off + (q / SAMAX) * NB * ldc + (q % SAMAX) * NB; E.dst_ld = (int)ldc; }
+                        } else if (is_rhs) { E.dst = rhsd + key * NB; E.dst_ld = 0; }
+                        else {
+                            const long long bi = key / nb, bj = key % nb;
+                            E.dst = Sd + (size_t)(bi * NB) * npad + bj * NB; E.dst_ld = npad;
+                            if (bi == bj) E.diag0 = (int)bi * NB;
+                        }
+                        for (; j < v.size() && v[j].key == key; ++j) {
+                            if (v[j].node < 0) continue;
+                            if (E.nsrc == SFOLD_SRC) { valid = false; break; }
+                            const NodeDesc& N = nodes[v[j].node];
+                            const long long ldu = (long long)N.na * NB;
+                            E.src[E.nsrc] = is_rhs ? Ud + N.u_off + ldu * ldu + (long long)v[j].a * NB : Ud + N.u_off + (long long)v[j].a * NB * ldu + (long long)v[j].b * NB;
+                            E.src_ld[E.nsrc] = (int)ldu;
+                            ++E.nsrc;
+                        }
+                        ents.push_back(E);
+                        i = j;
+                    }
+                };
+                C.e0 = (int)ents.size(); emit(blocks, false); C.e1 = (int)ents.size(); emit(rhss, true); C.e2 = (int)ents.size();
+            }
+            if (!valid) continue;
+        }
         // ---- upload
         std::vector<int> mask((size_t)h->npad_max, 0);
         for (int i = 0; i < npad; ++i) mask[i] = h->pos_param[i] >= 0;
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_cam_pos, h->cam_pos.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_posmask, mask.data(), mask.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_seg_blk, seg_blk.data(), seg_blk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         if (h->use_sparse) {
             SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             if (!rows.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_prow, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             if (P > 1) {
-                const size_t ntop = (size_t)(nb - h->top_blk) * NB, need = (size_t)P * (ntop * ntop + ntop);
-                if (need > h->topbuf_count) {
-                    int rc = dalloc(h, &h->d_topbuf, need); if (rc) return rc;
-                    h->topbuf_count = need;
-                }
+                int rc = SFMHIP_OK;
+                h->topbuf_count = u_total;
+                if (nodes.size() > h->nodes_cap) { rc = dalloc(h, &h->d_nodes, nodes.size()); if (rc) return rc; h->nodes_cap = nodes.size(); }
+                if (ents.size() + 1 > h->ents_cap) { rc = dalloc(h, &h->d_ents, ents.size() + 1); if (rc) return rc; h->ents_cap = ents.size() + 1; }
+                SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_nodes, nodes.data(), nodes.size() * sizeof(NodeDesc), hipMemcpyHostToDevice, ctx->stream));
+                if (!ents.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ents, ents.data(), ents.size() * sizeof(FoldEnt), hipMemcpyHostToDevice, ctx->stream));
+                h->lvl_first = first_of_level; h->top_node = n_par;
+                h->top_cleared = false;
             }
-        } else if (P > 1) continue;                                   // the dense path uses the natural single-segment layout
+        }
         h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;
         h->n_sblk = (int)sblk.size() / 2;
         {
@@ -802,7 +961,9 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->fix0 = h->o.fix_first_camera ? 1 : 0; h->fixK = h->o.fix_intrinsics ? 1 : 0;
     h->ncf = n_cam - h->fix0; h->koff = 6 * h->ncf; h->n = 6 * h->ncf + (h->fixK ? 0 : 4);
     h->npad = std::max(NB, round_up(h->n, NB)); h->nbk = h->npad / NB;
-    h->npad_max = h->npad + NB * 8;                 // room for the per-segment padding of the nested-dissection layout
+    // room for the per-node padding of the nested-dissection layout: up to solver_pmax leaves and as many separators
+    h->solver_pmax = 1; while (h->solver_pmax < 64 && h->solver_pmax * 16 <= h->ncf) h->solver_pmax *= 2;
+    h->npad_max = h->npad + NB * (2 * h->solver_pmax + 2);
     h->n_pt_blocks = std::max(1, ceil_div(n_pt, 256));
 #ifdef SFMHIP_EXPERIMENTS
     h->force_dense = getenv("SFMHIP_DENSE_SOLVER") != nullptr;
@@ -909,7 +1070,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));
     TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_campre, CAMPRE * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, CAMPRE * (size_t)n_cam));
-    TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_seg_blk, 16));
+    TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max));
     TRY_RC(dalloc(h, &h->d_prow_start, (size_t)h->npad_max / NB + 2)); TRY_RC(dalloc(h, &h->d_prow, ((size_t)h->npad_max / NB + 1) * SRMAX + 1));
     TRY_RC(dalloc(h, &h->d_Vinv, 6 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_bp, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_WK, 12 * (size_t)n_pt)); TRY_RC(dalloc(h, &h->d_colsq_p, 3 * (size_t)n_pt));

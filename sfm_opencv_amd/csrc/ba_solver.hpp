@@ -23,6 +23,7 @@
 #define SNB 32
 #define SLD 33          // LDS row stride in doubles: conflict-free row and column access
 #define SRMAX 8         // max sub-diagonal blocks per panel for the single-workgroup path
+#define SAMAX 8         // max blocks outside its own panel range that one elimination-tree node may reach
 #define STHREADS 512    // 8 waves, two per SIMD: wave 0 runs the pivot-block chain, the other seven share the trailing update
 #define SWAVES (STHREADS / 64)
 #define SSTAGE (4096 / STHREADS)   // staging loads in flight per thread: four 32x32 row blocks per round trip
@@ -62,6 +63,34 @@ struct DiagLds {
     double W[2 * SNB][SNB + 2];
     double G[2 * SNB][SPW + 2];         // one panel of the cross-panel update, handed from the MFMA result layout to lane = row
 };
+// ---- multi-level nested dissection of the camera chain ---------------------------------------------------------------
+// The camera chain is cut into P = 2^m leaf segments by P - 1 separators of `w` cameras (w = band width of the camera
+// graph).  Elimination order: leaves | separators that split sibling leaves | separators one level up | ... | the last
+// separators + the intrinsics ("top").  Nodes of one level are mutually independent: one workgroup each, one launch per
+// level; the top (a handful of panels) is factored by a single workgroup, which also starts the back-substitution.
+// A node's panels reach a few blocks outside its own range (the separators that bound it and the intrinsics block):
+// its updates to pairs of such blocks go to a PRIVATE update buffer U (na*32 square + na*32 right-hand side, zero on
+// entry), never to S itself, and the node that owns the lower-numbered block of a pair folds every descendant's
+// contribution into S before it factors its own panels -- in a fixed order, so the result is run-to-run identical.
+struct NodeDesc {
+    int k0, k1;             // own panel (32-block) range [k0, k1)
+    int na;                 // blocks outside [k0, k1) that its panels reach (after fill)
+    int anc[SAMAX];         // ... their indices, ascending
+    int e0, e1, e2;         // fold entries: [e0, e1) 32x32 blocks, [e1, e2) 32-entry pieces of the right-hand side
+    long long u_off;        // offset (doubles) of its update buffer in ubuf: [U (na*32)^2 | rhs na*32]
+};
+// One destination of a node's assembly step (extend-add of the multifrontal method): dst += the sources, in list order.
+// Sources are its CHILDREN's update-buffer blocks (child = node whose lowest outside block this node owns); destinations are
+// blocks of its own columns in S, or -- for pairs of blocks that lie outside this node too -- blocks of its own update
+// buffer (handed on to its parent in turn).  Every diagonal block of its own columns has an entry (possibly without
+// sources): the LM damping is applied to it in the same pass.
+#define SFOLD_SRC 8
+struct FoldEnt {
+    double* dst; const double* src[SFOLD_SRC];
+    int dst_ld, src_ld[SFOLD_SRC];
+    int nsrc, diag0;        // diag0 >= 0: dst is a diagonal block of S whose first row has this position (damping applies)
+};
+
 struct SolverLds : DiagLds {
     double B[SRMAX * SNB + 1][SLD];     // stacked row blocks of the panel + the rhs row; the y vector in the backward phase
     double Red[SNB][SLD];
@@ -72,6 +101,7 @@ struct SolverLds : DiagLds {
     // (the idle wave fills the next panel's table while the others walk the current one)
     int4 Pair[2][SRMAX * (SRMAX + 1) / 2];
     int PairLd[2][SRMAX * (SRMAX + 1) / 2];
+    int Anc[SAMAX];                     // the node's outside blocks (slot = position in this list)
 };
 
 // One wave: in-place Cholesky of the 32x32 block in s.D (lower) AND the inverse of the factor, in the same 32 pivot steps:
@@ -180,13 +210,14 @@ __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 
 // ------------------------------------------------------------------------------------------------
 // Panel sweeps shared by the kernels below.  prow_start[k] .. prow_start[k+1]: ascending block rows i > k with
-// L_ik != 0 (after fill).  Blocks >= top_blk form the "top" system (separators + intrinsics) shared by several
-// segment workgroups: updates whose target lies entirely in the top are accumulated in the caller's PRIVATE
-// buffers (topA: ntop x ntop, toprhs: ntop) and summed later in a fixed order (deterministic, no atomics).
+// L_ik != 0 (after fill).  A node sweeps its own panels [k0, k1); with HAS_EXT, updates whose target lies entirely
+// outside that range (both blocks >= k1: they belong to later nodes) are accumulated in the node's PRIVATE update buffer
+// (extA: na*32 square with row stride ext_ld, extrhs: na*32; slot of a block = its position in s.Anc) and folded into S
+// by their owner later, in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
 struct SolverPlan {
     const int* prow_start; const int* prow;
-    int nb, top_blk;             // top_blk == nb: no shared top
+    int nb, top_blk;             // blocks; top_blk: first block of the serially factored top (nb: none)
     int dbg;                     // timing experiments only (SFMHIP_EXP_SOLVER): skip phases, results are garbage
     long long* stamps;           // diagnostic (SFMHIP_SOLVER_STAMPS): s_memtime at the phase boundaries of each panel, 8 per panel
     double* linv;                // (L_kk^-1)' of every pivot block, 32x32 each, written by the forward sweep for the backward one
@@ -195,9 +226,9 @@ struct SolverPlan {
     const double* damp_diagU; const int* damp_mask; double damp_radius, damp_min, damp_max;
 };
 
-template <bool HAS_TOP>
+template <bool HAS_EXT>
 __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict__ A, int ld, int k0, int k1, const SolverPlan pl,
-                                               double* __restrict__ rhs, double* __restrict__ topA, double* __restrict__ toprhs)
+                                               double* __restrict__ rhs, double* __restrict__ extA, int ext_ld, int na, double* __restrict__ extrhs)
 {
     // Look-ahead schedule.  Per panel k (entering with L_kk and its inverse in s.D / s.W, every earlier update visible):
     //   1. all waves stage the panel's row blocks (global -> s.B), write L_kk out                          | lds barrier
@@ -210,7 +241,8 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
     // (11k cycles together): measured per panel 29.6k -> see profiles/README.md.
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: role tests become scalar branches
     const int r0 = tid >> 5, c = tid & 31;
-    const int ntop = (pl.nb - pl.top_blk) * SNB;
+    // slot of an outside block in the node's update buffer (s.Anc is ascending, na <= SAMAX)
+    auto ext_slot = [&](int b) { int q = 0; for (int a = 1; a < SAMAX; ++a) q += (a < na && s.Anc[a] <= b) ? 1 : 0; return q; };
     // The plan arrays are read-only for the kernel: through a constant-address-space pointer their loads are scalar (s_load).
     // As plain global loads (the kernel also stores, so the compiler must assume aliasing) the two prow_start reads at the
     // top of every panel came with an s_waitcnt vmcnt(0) -- a wait for every outstanding store and atomic of the wave,
@@ -231,7 +263,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             int qi = 0, qj = pr; while (qj > qi) { qj -= qi + 1; ++qi; }
             const int bi = Rw[qi], bjb = Rw[qj];
             double* dst; int dld;
-            if (HAS_TOP && bjb >= pl.top_blk) { dst = topA + (size_t)((bi - pl.top_blk) * SNB) * ntop + (bjb - pl.top_blk) * SNB; dld = ntop; }
+            if (HAS_EXT && bjb >= k1) { dst = extA + (size_t)(ext_slot(bi) * SNB) * ext_ld + ext_slot(bjb) * SNB; dld = ext_ld; }
             else { dst = A + (size_t)(bi * SNB) * ld + bjb * SNB; dld = ld; }
             const unsigned long long u = (unsigned long long)dst;
             s.Pair[kk & 1][pr] = make_int4(qi * SNB, qj * SNB, (int)(unsigned)u, (int)(unsigned)(u >> 32));
@@ -269,7 +301,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
             rhs_old[u] = 0.0;
             if (wave == 4 && t < R * SNB) {
                 const int bi = Rows[t >> 5];
-                rhs_old[u] = (HAS_TOP && bi >= pl.top_blk) ? toprhs[(bi - pl.top_blk) * SNB + (t & 31)] : rhs[bi * SNB + (t & 31)];
+                rhs_old[u] = (HAS_EXT && bi >= k1) ? extrhs[ext_slot(bi) * SNB + (t & 31)] : rhs[bi * SNB + (t & 31)];
             }
         }
         // 1. No staging pass: every wave requests the 16 rows of its own solve tile straight into the MFMA operand layout
@@ -419,7 +451,7 @@ __device__ __forceinline__ bool forward_panels(SolverLds& s, double* __restrict_
                         for (int j = 0; j < 4; ++j) v4[j] = fma(s.B[t][m + j], s.B[R * SNB][m + j], v4[j]);
                     const double v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
                     const int bi = Rows[t >> 5];
-                    if (HAS_TOP && bi >= pl.top_blk) toprhs[(bi - pl.top_blk) * SNB + (t & 31)] = rhs_old[u] - v;
+                    if (HAS_EXT && bi >= k1) extrhs[ext_slot(bi) * SNB + (t & 31)] = rhs_old[u] - v;
                     else rhs[bi * SNB + (t & 31)] = rhs_old[u] - v;
                     if (u == 0 && t < SNB) rhs_next = rhs_old[u] - v;       // rows 0..31 are block Rows[0] (= k + 1 if next_diag)
                 }
@@ -504,7 +536,64 @@ __device__ __forceinline__ void damp_rows(double* __restrict__ A, int ld, const 
     }
 }
 
-// single workgroup: whole factorisation + both substitutions (no shared top)
+// Assembly step of a node (see FoldEnt).  A thread owns one 16-byte element pair of every destination block; DB destinations
+// per batch with every load of the batch in flight before the first add (a dependent load from another workgroup's buffer
+// is a ~2 us round trip); sources are summed in list order (fixed => deterministic).  NSRC sources per destination are
+// requested up front, longer lists continue one by one.
+template <int DB, int NSRC>
+__device__ __forceinline__ void fold_node(const FoldEnt* __restrict__ ents, int e0, int e1, int e2, const SolverPlan& pl)
+{
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, c = (tid & 15) * 2;
+    for (int d0 = e0; d0 < e1; d0 += DB) {
+        v2d acc[DB], t[DB][NSRC];
+        double dmp[DB]; int msk[DB];
+#pragma unroll
+        for (int u = 0; u < DB; ++u)
+            if (d0 + u < e1) {
+                const FoldEnt& E = ents[d0 + u];
+                acc[u] = *(const v2d*)(E.dst + (size_t)r * E.dst_ld + c);
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q)
+                    if (q < E.nsrc) t[u][q] = *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
+                dmp[u] = 0.0; msk[u] = 1;
+                if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) { dmp[u] = pl.damp_diagU[E.diag0 + r]; msk[u] = pl.damp_mask[E.diag0 + r]; }
+            }
+#pragma unroll
+        for (int u = 0; u < DB; ++u)
+            if (d0 + u < e1) {
+                const FoldEnt& E = ents[d0 + u];
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q)
+                    if (q < E.nsrc) acc[u] += t[u][q];
+                for (int q = NSRC; q < E.nsrc; ++q) acc[u] += *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
+                if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) {      // this thread's pair holds the diagonal element (r, r)
+                    const double add = fmin(fmax(dmp[u], pl.damp_min), pl.damp_max) / pl.damp_radius;
+                    if (r & 1) acc[u].y = msk[u] ? acc[u].y + add : 1.0; else acc[u].x = msk[u] ? acc[u].x + add : 1.0;
+                }
+                *(v2d*)(E.dst + (size_t)r * E.dst_ld + c) = acc[u];
+            }
+    }
+    // right-hand side: one thread per (destination, element), 16 destinations per batch
+    for (int d0 = e1; d0 < e2; d0 += STHREADS / SNB) {
+        const int di = d0 + (tid >> 5), e = tid & 31;
+        if (di < e2) {
+            const FoldEnt& E = ents[di];
+            double v = E.dst[e];
+            double tq[NSRC];
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q)
+                if (q < E.nsrc) tq[q] = E.src[q][e];
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q)
+                if (q < E.nsrc) v += tq[q];
+            for (int q = NSRC; q < E.nsrc; ++q) v += E.src[q][e];
+            E.dst[e] = v;
+        }
+    }
+}
+
+// single workgroup: whole factorisation + both substitutions (no dissection)
 __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restrict__ A, int ld, SolverPlan pl,
                                                                double* __restrict__ rhs, double* __restrict__ y, int* __restrict__ err)
 {
@@ -512,7 +601,7 @@ __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restric
     const int tid = threadIdx.x;
     damp_rows(A, ld, pl, 0, pl.nb * SNB);
     __syncthreads();
-    const bool ok = forward_panels<false>(s, A, ld, 0, pl.nb, pl, rhs, nullptr, nullptr);
+    const bool ok = forward_panels<false>(s, A, ld, 0, pl.nb, pl, rhs, nullptr, 0, 0, nullptr);
     if (!ok && tid == 0) *err = 2;
     double* sy = &s.B[0][0];
     const int n = pl.nb * SNB;
@@ -522,85 +611,54 @@ __global__ __launch_bounds__(STHREADS) void chol_sparse_kernel(double* __restric
     for (int i = tid; i < n; i += STHREADS) y[i] = sy[i];
 }
 
-// ---- nested dissection over the camera chain: P segment workgroups, then one top workgroup, then P again -------
-// seg_blk[s] .. seg_blk[s+1]: panel range of segment s (block aligned); private top buffers: topbuf + s*(ntop^2 + ntop)
-__global__ __launch_bounds__(STHREADS) void chol_nd_forward_kernel(double* __restrict__ A, int ld, SolverPlan pl, const int* __restrict__ seg_blk,
-                                                                   double* __restrict__ rhs, double* __restrict__ topbuf, int* __restrict__ err)
+// ---- one level of the dissection: a workgroup per node ------------------------------------------------------------
+__global__ __launch_bounds__(STHREADS) void chol_node_forward_kernel(double* __restrict__ A, int ld, SolverPlan pl, const NodeDesc* __restrict__ nodes, int first,
+                                                                     double* __restrict__ rhs, double* __restrict__ ubuf,
+                                                                     const FoldEnt* __restrict__ ents, int* __restrict__ err)
 {
     __shared__ SolverLds s;
-    const int seg = blockIdx.x;
-    const size_t ntop = (size_t)(pl.nb - pl.top_blk) * SNB;
-    double* topA = topbuf + (size_t)seg * (ntop * ntop + ntop);
-    damp_rows(A, ld, pl, seg_blk[seg] * SNB, seg_blk[seg + 1] * SNB);
+    const NodeDesc nd = nodes[first + blockIdx.x];
+    if (threadIdx.x < SAMAX) s.Anc[threadIdx.x] = nd.anc[threadIdx.x];
+    if (nd.e0 == nd.e2) damp_rows(A, ld, pl, nd.k0 * SNB, nd.k1 * SNB);       // a leaf: nothing to assemble, only the damping
+    else fold_node<8, 2>(ents, nd.e0, nd.e1, nd.e2, pl);                       // two children per separator
     __syncthreads();
-    const bool ok = forward_panels<true>(s, A, ld, seg_blk[seg], seg_blk[seg + 1], pl, rhs, topA, topA + ntop * ntop);
+    double* U = ubuf + nd.u_off;
+    const int ldu = nd.na * SNB;
+    const bool ok = forward_panels<true>(s, A, ld, nd.k0, nd.k1, pl, rhs, U, ldu, nd.na, U + (size_t)ldu * ldu);
     if (!ok && threadIdx.x == 0) *err = 2;
 }
 
-__global__ __launch_bounds__(STHREADS) void chol_nd_top_kernel(double* __restrict__ A, int ld, SolverPlan pl, int nseg,
-                                                               double* __restrict__ rhs, const double* __restrict__ topbuf,
-                                                               double* __restrict__ y, int* __restrict__ err)
+// the top node (last separators + intrinsics): assemble, factor serially, solve, and its share of the back-substitution
+__global__ __launch_bounds__(STHREADS) void chol_top_kernel(double* __restrict__ A, int ld, SolverPlan pl, const NodeDesc* __restrict__ nodes, int top_node,
+                                                            double* __restrict__ rhs, const FoldEnt* __restrict__ ents,
+                                                            double* __restrict__ y, int* __restrict__ err)
 {
     __shared__ SolverLds s;
     const int tid = threadIdx.x;
-    const int ntop = (pl.nb - pl.top_blk) * SNB, t0 = pl.top_blk * SNB;
-    // fold the segments' private contributions into the top system, in segment order.  Batches of FB elements per
-    // thread with every load of the batch in flight before the first add: one element at a time this loop paid an L2
-    // round trip per element (36 elements per thread at ntop = 96: ~50 us of an 89 us kernel).
-    {
-        constexpr int FB = 6;
-        const size_t seg_stride = (size_t)ntop * ntop + ntop;
-        for (int e0 = tid; e0 < ntop * ntop; e0 += FB * STHREADS) {
-            double v[FB], c[FB][SRMAX];
-#pragma unroll
-            for (int b = 0; b < FB; ++b) {
-                const int e = e0 + b * STHREADS;
-                if (e < ntop * ntop) {
-                    v[b] = A[(size_t)(t0 + e / ntop) * ld + t0 + e % ntop];
-#pragma unroll
-                    for (int sg = 0; sg < SRMAX; ++sg) if (sg < nseg) c[b][sg] = topbuf[(size_t)sg * seg_stride + e];
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < FB; ++b) {
-                const int e = e0 + b * STHREADS;
-                if (e < ntop * ntop) {
-                    double acc = v[b];
-#pragma unroll
-                    for (int sg = 0; sg < SRMAX; ++sg) if (sg < nseg) acc += c[b][sg];
-                    A[(size_t)(t0 + e / ntop) * ld + t0 + e % ntop] = acc;
-                }
-            }
-        }
-        for (int i = tid; i < ntop; i += STHREADS) {
-            double v = rhs[t0 + i];
-            for (int sg = 0; sg < nseg; ++sg) v += topbuf[(size_t)sg * seg_stride + (size_t)ntop * ntop + i];
-            rhs[t0 + i] = v;
-        }
-    }
+    const NodeDesc nd = nodes[top_node];
+    const int t0 = nd.k0 * SNB, ntop = (nd.k1 - nd.k0) * SNB;
+    fold_node<2, SFOLD_SRC>(ents, nd.e0, nd.e1, nd.e2, pl);       // up to 8 children (the nodes of the last parallel level)
     __syncthreads();
-    damp_rows(A, ld, pl, t0, t0 + ntop);
-    __syncthreads();
-    SolverPlan top = pl; top.top_blk = pl.nb;
-    const bool ok = forward_panels<false>(s, A, ld, pl.top_blk, pl.nb, top, rhs, nullptr, nullptr);
+    const bool ok = forward_panels<false>(s, A, ld, nd.k0, nd.k1, pl, rhs, nullptr, 0, 0, nullptr);
     if (!ok && tid == 0) *err = 2;
     double* sy = &s.B[0][0];
     for (int i = tid; i < ntop; i += STHREADS) sy[t0 + i] = rhs[t0 + i];
     __syncthreads();
-    backward_panels(s, A, ld, pl.top_blk, pl.nb, pl, sy);
+    backward_panels(s, A, ld, nd.k0, nd.k1, pl, sy);
     for (int i = tid; i < ntop; i += STHREADS) y[t0 + i] = sy[t0 + i];
 }
 
-__global__ __launch_bounds__(STHREADS) void chol_nd_backward_kernel(const double* __restrict__ A, int ld, SolverPlan pl, const int* __restrict__ seg_blk,
-                                                                    const double* __restrict__ rhs, double* __restrict__ y)
+__global__ __launch_bounds__(STHREADS) void chol_node_backward_kernel(const double* __restrict__ A, int ld, SolverPlan pl, const NodeDesc* __restrict__ nodes, int first,
+                                                                      const double* __restrict__ rhs, double* __restrict__ y)
 {
     __shared__ SolverLds s;
-    const int tid = threadIdx.x, seg = blockIdx.x;
-    const int k0 = seg_blk[seg], k1 = seg_blk[seg + 1];
+    const int tid = threadIdx.x;
+    const NodeDesc nd = nodes[first + blockIdx.x];
     double* sy = &s.B[0][0];
-    for (int i = pl.top_blk * SNB + tid; i < pl.nb * SNB; i += STHREADS) sy[i] = y[i];
-    for (int i = k0 * SNB + tid; i < k1 * SNB; i += STHREADS) sy[i] = rhs[i];
+    // y of the outside blocks its panels reach (solved by later nodes), z of its own panels
+    for (int i = tid; i < nd.na * SNB; i += STHREADS) { const int b = nd.anc[i >> 5]; sy[b * SNB + (i & 31)] = y[b * SNB + (i & 31)]; }
+    for (int i = nd.k0 * SNB + tid; i < nd.k1 * SNB; i += STHREADS) sy[i] = rhs[i];
     __syncthreads();
-    backward_panels(s, A, ld, k0, k1, pl, sy);
-    for (int i = k0 * SNB + tid; i < k1 * SNB; i += STHREADS) y[i] = sy[i];
+    backward_panels(s, A, ld, nd.k0, nd.k1, pl, sy);
+    for (int i = nd.k0 * SNB + tid; i < nd.k1 * SNB; i += STHREADS) y[i] = sy[i];
 }
