@@ -36,9 +36,9 @@ I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x bf16 dense (~2.5 PFLOP/s)
 # TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from separate rocprofv3 --pmc passes over this command at
 # N=1 / C4: recorded figures, NOT measured in the run that prints them (counters are not collectable in-process)
 # a write-only stream on this part (experiments/wbw*.hip, profiles/README.md): what a kernel that only stores can reach
-STORE_CEILING_GBS = 5500.0
-STORE_CEILING_SOURCE = "experiments/wbw2.hip: 400 MB plain-store stream, best of the shapes tried (profiles/README.md)"
-SOLVER_KERNEL = "chol_nd_forward_kernel"
+STORE_CEILING_GBS = 5760.0
+STORE_CEILING_SOURCE = "experiments/wbw4.hip: 400 MB write-only streams, best of the shapes tried (16-byte stores, 16k workgroups: 5.76 TB/s; the guide's 6.0-6.2 TB/s figure was not reproduced, profiles/README.md)"
+SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissection (the longest solver launch)
 RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (2.977e8, "profiles/r01_traffic_pmc.md"),
                     "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md")}
 

@@ -53,6 +53,12 @@ def lib():
         if not os.path.exists(_SO):
             build()
         _lib = C.CDLL(_SO)
+        # OpenMP would start one thread per hardware thread of the HOST (hundreds on a GPU box whose container owns 16 cores):
+        # spinning barriers oversubscribed like that take minutes for a one-second solve.  Default to the cores we may run on.
+        try:
+            _lib.orc_set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        except (AttributeError, OSError):
+            _lib.orc_set_num_threads(8)
         _lib.orc_ratio_filter.restype = C.c_int
         _lib.orc_ba_solve.restype = C.c_int
         _lib.orc_ba_reduced_system.restype = C.c_int

@@ -35,3 +35,27 @@ def write_features(path, K, key_points, descriptors, colors=None, poses=None):
             if poses is not None:
                 R, T = poses[i]
                 f.write(np.asarray(R, "<f8").reshape(9).tobytes()); f.write(np.asarray(T, "<f8").reshape(3).tobytes())
+
+
+def read_features(path):
+    """-> dict(K 3x3, key_points [KEYPOINT arrays], descriptors [uint8 / float32 matrices], colors [(n,3) uint8], poses or None)"""
+    raw = open(path, "rb").read()
+    assert raw[:8] == MAGIC
+    n_img = struct.unpack_from("<i", raw, 8)[0]
+    K = np.frombuffer(raw, "<f8", 9, 12).reshape(3, 3).copy()
+    has_poses = struct.unpack_from("<i", raw, 84)[0]
+    off = 88
+    kps, descs, cols, poses = [], [], [], []
+    for _ in range(n_img):
+        n_kp, typ, ncol = struct.unpack_from("<iii", raw, off); off += 12
+        kps.append(np.frombuffer(raw, KEYPOINT, n_kp, off).copy()); off += 28 * n_kp
+        if typ == 5:
+            descs.append(np.frombuffer(raw, "<f4", n_kp * ncol, off).reshape(n_kp, ncol).copy()); off += 4 * n_kp * ncol
+        else:
+            d = np.frombuffer(raw, np.uint8, n_kp * ncol, off).reshape(n_kp, ncol).copy(); off += n_kp * ncol
+            descs.append(d.astype(np.float32) if typ == 100 else d)
+        cols.append(np.frombuffer(raw, np.uint8, 3 * n_kp, off).reshape(n_kp, 3).copy()); off += 3 * n_kp
+        if has_poses:
+            R = np.frombuffer(raw, "<f8", 9, off).reshape(3, 3).copy(); T = np.frombuffer(raw, "<f8", 3, off + 72).copy(); off += 96
+            poses.append((R, T))
+    return dict(K=K, key_points=kps, descriptors=descs, colors=cols, poses=poses if has_poses else None)

@@ -8,12 +8,17 @@
 //
 //   features file, little-endian:
 //     char magic[8] = "SFMFEAT1";  int32 n_img;  double K[9];  int32 has_poses;
-//     per image:  int32 n_kp, desc_type (0 = CV_8U, 5 = CV_32F), desc_cols;
+//     per image:  int32 n_kp, desc_type (0 = CV_8U, 5 = CV_32F, 100 = CV_32F rows stored as one byte per value: integer-valued
+//                 SIFT descriptors), desc_cols;
 //                 sfm_keypoint kp[n_kp];  descriptor rows;  uint8 bgr[n_kp][3];
 //                 if has_poses: double R[9], T[3]      (world -> camera; used with --poses-from-file only)
 #pragma once
+#include <dirent.h>
+#include <sys/stat.h>
+
 #include <iostream>
 
+#include "sfm_features.hpp"
 #include "sfm_geometry.hpp"
 
 namespace sfm {
@@ -43,11 +48,15 @@ inline bool read_features(const std::string& path, Features& f)
     for (int i = 0; i < n_img && in; ++i) {
         int32_t n_kp = 0, type = 0, cols = 0;
         in.read((char*)&n_kp, 4); in.read((char*)&type, 4); in.read((char*)&cols, 4);
-        if (!in || n_kp < 0 || cols < 0 || (type != CV_8U && type != CV_32F)) { printf("[Err]: corrupt features file.\n"); return false; }
+        if (!in || n_kp < 0 || cols < 0 || (type != CV_8U && type != CV_32F && type != 100)) { printf("[Err]: corrupt features file.\n"); return false; }
         std::vector<KeyPoint> kp((size_t)n_kp);
         in.read((char*)kp.data(), (std::streamsize)sizeof(KeyPoint) * n_kp);
-        Mat d(n_kp, cols, type);
-        in.read((char*)d.buf.data(), (std::streamsize)d.buf.size());
+        Mat d(n_kp, cols, type == 100 ? (int)CV_32F : type);
+        if (type == 100) {
+            std::vector<uint8_t> packed((size_t)n_kp * cols);
+            in.read((char*)packed.data(), (std::streamsize)packed.size());
+            for (size_t q = 0; q < packed.size(); ++q) d.ptr<float>()[q] = (float)packed[q];
+        } else in.read((char*)d.buf.data(), (std::streamsize)d.buf.size());
         std::vector<Vec3b> col((size_t)n_kp);
         in.read((char*)col.data(), (std::streamsize)3 * n_kp);
         Mat R(3, 3, CV_64F), T(3, 1, CV_64F);
@@ -61,6 +70,59 @@ inline bool read_features(const std::string& path, Features& f)
     }
     return (bool)in;
 }
+
+// the same file from extracted features (CV_32F descriptors whose values are all integers in [0, 255] are stored packed)
+inline bool write_features(const std::string& path, const Features& f)
+{
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return false;
+    out.write("SFMFEAT1", 8);
+    const int32_t n_img = (int32_t)f.key_points_for_all.size(), has_poses = 0;
+    out.write((const char*)&n_img, 4); out.write((const char*)f.K.ptr<double>(), 72); out.write((const char*)&has_poses, 4);
+    for (int i = 0; i < n_img; ++i) {
+        const Mat& d = f.descriptor_for_all[i];
+        bool packable = d.type == CV_32F;
+        if (packable) for (size_t q = 0; q < (size_t)d.rows * d.cols && packable; ++q) { const float v = d.ptr<float>()[q]; packable = v >= 0 && v <= 255 && v == (float)(int)v; }
+        const int32_t n_kp = d.rows, type = packable ? 100 : d.type, cols = d.cols;
+        out.write((const char*)&n_kp, 4); out.write((const char*)&type, 4); out.write((const char*)&cols, 4);
+        out.write((const char*)f.key_points_for_all[i].data(), (std::streamsize)sizeof(KeyPoint) * n_kp);
+        if (packable) { std::vector<uint8_t> p((size_t)n_kp * cols); for (size_t q = 0; q < p.size(); ++q) p[q] = (uint8_t)d.ptr<float>()[q]; out.write((const char*)p.data(), (std::streamsize)p.size()); }
+        else out.write((const char*)d.buf.data(), (std::streamsize)d.buf.size());
+        out.write((const char*)f.colors_for_all[i].data(), (std::streamsize)3 * n_kp);
+    }
+    return (bool)out;
+}
+
+// get_files_format (NView:1303-1330) for a POSIX directory: regular files whose name ends in `format`, sorted by name
+// (the reference relies on the directory order of _findfirst, alphabetical on NTFS; it does not recurse into this use)
+inline int get_files_format(const std::string& path, const std::string& format, std::vector<std::string>& files)
+{
+    DIR* d = opendir(path.c_str());
+    if (!d) return 0;
+    std::vector<std::string> names;
+    while (dirent* e = readdir(d)) {
+        const std::string n = e->d_name;
+        if (n.size() > format.size() && n.compare(n.size() - format.size(), format.size(), format) == 0) names.push_back(n);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end());
+    for (const auto& n : names) files.push_back(path + "/" + n);
+    return (int)files.size();
+}
+
+// K: the reference hard-codes it (NView:1353-1356) and asks for it to become an input (TODO at 1358): `<dir>/K.txt` with
+// "fx fy cx cy" if present, else the reference's matrix
+inline Mat load_K(const std::string& dir)
+{
+    Mat K = Mat::eye3();
+    double v[4] = { 2826.561, 2826.519, 1835.259, 1370.103 };
+    std::ifstream f(dir + "/K.txt");
+    if (f) { double t[4]; if (f >> t[0] >> t[1] >> t[2] >> t[3]) for (int i = 0; i < 4; ++i) v[i] = t[i]; }
+    K.at<double>(0, 0) = v[0]; K.at<double>(1, 1) = v[1]; K.at<double>(0, 2) = v[2]; K.at<double>(1, 2) = v[3];
+    return K;
+}
+
+inline bool is_directory(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 
 inline std::vector<uint8_t> mask_vector(const Mat& mask) { return std::vector<uint8_t>(mask.ptr<uint8_t>(), mask.ptr<uint8_t>() + (size_t)mask.rows * mask.cols); }
 
@@ -105,6 +167,9 @@ struct PipelineOptions {
     bool poses_from_file = false;          // skip find_transform / solvePnPRansac, take R, T of every frame from the features file
     bool write_back_poses = false;         // structure_ba.yml with the optimised poses (the reference writes the pre-BA ones)
     bool print_offsets = true;             // the per-point "Point3d i offset" lines (NView:1494-1498)
+    int max_features = 0;                  // directory input: keep the strongest N key points per image (0: all, like the reference)
+    std::string save_features;             // directory input: also write the extracted features to this file
+    bool features_only = false;            // ... and stop there
 };
 
 // main() of NViewReconstuct.cpp from "match_features_for_all" on (NView:1369-1517)
@@ -234,7 +299,7 @@ inline int run_twoview(Features& f, const PipelineOptions& opt)
 inline int driver_main(int argc, char** argv, bool nview)
 {
     if (argc < 2 || std::string(argv[1]).empty()) {
-        printf("[Warning]: empty dataset path.\nusage: %s <features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet]\n", argv[0]);
+        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.ppm) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only]\n", argv[0]);
         return 0;
     }
     PipelineOptions opt;
@@ -244,12 +309,29 @@ inline int driver_main(int argc, char** argv, bool nview)
         if (a == "--poses-from-file") opt.poses_from_file = true;
         else if (a == "--write-back-poses") opt.write_back_poses = true;
         else if (a == "--quiet") opt.print_offsets = false;
+        else if (a == "--features-only") opt.features_only = true;
+        else if (a.rfind("--max-features=", 0) == 0) opt.max_features = std::atoi(a.c_str() + 15);
+        else if (a.rfind("--save-features=", 0) == 0) opt.save_features = a.substr(16);
         else if (positional++ == 0) opt.out_dir = a;
     }
     Features f;
-    if (!read_features(argv[1], f)) return 1;
-    printf("Total %d image files.\n", (int)f.key_points_for_all.size());
+    if (is_directory(argv[1])) {
+        // the reference's own entry: a directory of images (binary .ppm / .pgm here: no JPEG decoder is built)
+        std::vector<std::string> img_names;
+        int n_files = get_files_format(argv[1], ".ppm", img_names);
+        if (n_files == 0) n_files = get_files_format(argv[1], ".pgm", img_names);
+        printf("Total %d image files.\n", n_files);
+        f.K = load_K(argv[1]);
+        extract_features(img_names, f.key_points_for_all, f.descriptor_for_all, f.colors_for_all, opt.max_features);
+        f.file_rotations.assign(f.key_points_for_all.size(), Mat()); f.file_motions.assign(f.key_points_for_all.size(), Mat());
+        if (!opt.save_features.empty() && !write_features(opt.save_features, f)) printf("[Warning]: cannot write %s\n", opt.save_features.c_str());
+    } else {
+        if (!read_features(argv[1], f)) return 1;
+        printf("Total %d image files.\n", (int)f.key_points_for_all.size());
+    }
+    if (opt.features_only) return 0;
     if (opt.poses_from_file && !f.has_poses) { printf("[Err]: the features file holds no poses.\n"); return 1; }
+    if (f.key_points_for_all.size() < 2) { printf("[Err]: fewer than two usable images.\n"); return 1; }
     if (!context()) return 1;                               // no GPU: fail loudly, there is no CPU path
     const int rc = nview ? run_nview(f, opt) : run_twoview(f, opt);
     return rc == 0 ? 0 : 1;

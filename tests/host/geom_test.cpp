@@ -5,6 +5,8 @@
 //   geom_test pnp <in.bin> <out.bin>         in: K(9) n, obj (n x 3 float), img (n x 2 float)
 //                                            out: ok(int) rvec(3) T(3) R(9) n_inliers
 //   geom_test rodrigues <in.bin> <out.bin>   in: n, rvec (n x 3 double)   out: R (n x 9), back (n x 3)
+//   geom_test features <image.ppm> <out.bin> [max]  out: n, key points (n x 28 B), descriptors (n x 128 float), colours (n x 3)
+#include "../../sfm_opencv_amd/host/sfm_features.hpp"
 #include "../../sfm_opencv_amd/host/sfm_geometry.hpp"
 using namespace sfm;
 
@@ -12,6 +14,16 @@ int main(int argc, char** argv)
 {
     if (argc < 4) return 2;
     const std::string mode = argv[1];
+    if (mode == "features") {
+        std::vector<std::string> names = { argv[2] };
+        std::vector<std::vector<KeyPoint>> kps; std::vector<Mat> descs; std::vector<std::vector<Vec3b>> cols;
+        extract_features(names, kps, descs, cols, argc > 4 ? std::atoi(argv[4]) : 0);
+        std::ofstream o(argv[3], std::ios::binary);
+        const int n = kps.empty() ? 0 : (int)kps[0].size();
+        o.write((const char*)&n, 4);
+        if (n) { o.write((const char*)kps[0].data(), (std::streamsize)sizeof(KeyPoint) * n); o.write((const char*)descs[0].buf.data(), (std::streamsize)descs[0].buf.size()); o.write((const char*)cols[0].data(), 3 * (std::streamsize)n); }
+        return 0;
+    }
     std::ifstream in(argv[2], std::ios::binary);
     std::ofstream out(argv[3], std::ios::binary);
     auto rd = [&](void* p, size_t n) { in.read((char*)p, (std::streamsize)n); };

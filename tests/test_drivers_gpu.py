@@ -156,3 +156,54 @@ def test_twoview_driver(drivers, tmp_path):
     assert out.returncode == 0 and "Init R:" in out.stdout
     y2 = formats.read_structure_yml(tmp_path / "structure.yml")
     assert abs(np.linalg.norm(y2["motions"][1]) - 1.0) < 1e-9 and y2["points"].shape[0] > 0.9 * len(xyz)
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_nview_driver_on_the_crazyhorse_sequence(drivers, tmp_path):
+    """BASELINE.json configs[1]: NViewReconstuct on dataset/crazyhorse, full sequence, BA to convergence.  Input: the
+    features fixture made from the reference's seven JPEGs by this repo's own SIFT (tests/golden/make_crazyhorse_features.py;
+    the reference's AKAZE is not rebuilt, so this is a quality test: parity unpinned).  Everything after the features runs
+    here: matching, essential matrix, PnP, triangulation, fusion, BA, normals, the three output files."""
+    out = subprocess.run([drivers[0], os.path.join(GOLD, "crazyhorse_features.bin"), str(tmp_path), "--quiet"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    log = out.stdout
+    assert "Total 7 image files." in log and "Frame 5 point cloud fused" in log and "Save structure done." in log
+    v = re.search(r"#views: (\d+)\n #residuals: (\d+)\n Initial RMSE\(pixel\): ([0-9.eE+-]+)\n Final   RMSE\(pixel\): ([0-9.eE+-]+)", log)
+    assert v, log[-2000:]
+    views, nres, r0, r1 = int(v.group(1)), int(v.group(2)), float(v.group(3)), float(v.group(4))
+    assert views == 7 and nres > 2000
+    assert r1 < 0.5 and r1 < r0                                   # sub-pixel after BA (0.18 px when the fixture was made)
+    y0 = formats.read_structure_yml(tmp_path / "structure.yml"); y1 = formats.read_structure_yml(tmp_path / "structure_ba.yml")
+    assert len(y0["rotations"]) == 7 and y0["points"].shape[0] > 350 and y1["points"].shape == y0["points"].shape
+    assert np.array_equal(y0["points"], y0["points"].astype(np.float32).astype(np.float64))        # float32-exact before BA (NView:1155)
+    ply = formats.read_ply_binary(tmp_path / "structure_ba.ply")
+    assert len(ply) == y1["points"].shape[0]
+    # the cameras sweep around the object: monotone rotation about the vertical axis, baseline growing along x
+    yaw = [np.degrees(np.arctan2(R[0, 2], R[2, 2])) for R in y0["rotations"]]
+    assert all(b > a for a, b in zip(yaw, yaw[1:])) and 5 < yaw[-1] < 40
+    tx = [float(np.asarray(T).reshape(3)[0]) for T in y0["motions"]]
+    assert all(b < a for a, b in zip(tx, tx[1:]))
+    # the bulk of the structure lies in front of the first camera at a sensible depth (unit = first baseline)
+    z = y1["points"][:, 2]
+    assert np.median(z) > 2 and (z > 0).mean() > 0.95
+
+
+def test_twoview_driver_on_crazyhorse(drivers, tmp_path):
+    """BASELINE.json configs[0]: TwoViewReconstruct on dataset/crazyhorse (first two images of the features fixture)."""
+    out = subprocess.run([drivers[1], os.path.join(GOLD, "crazyhorse_features.bin"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "successful!!!" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    y = formats.read_structure_yml(tmp_path / "structure.yml")
+    assert len(y["rotations"]) == 2 and np.array_equal(y["rotations"][0], np.eye(3)) and not y["motions"][0].any()
+    assert abs(np.linalg.norm(y["motions"][1]) - 1.0) < 1e-9 and abs(np.linalg.det(y["rotations"][1]) - 1.0) < 1e-9
+    assert y["points"].shape[0] > 120 and (y["points"][:, 2] > 0).mean() > 0.95
+    # reprojection of the triangulated points into both views with the recovered pose: sub-pixel
+    from sfm_opencv_amd import features_io
+    f = features_io.read_features(os.path.join(GOLD, "crazyhorse_features.bin"))
+    K = f["K"]
+    X = y["points"]
+    for R, T in ((np.eye(3), np.zeros(3)), (y["rotations"][1], y["motions"][1].reshape(3))):
+        p = X @ R.T + T
+        uv = np.stack([K[0, 0] * p[:, 0] / p[:, 2] + K[0, 2], K[1, 1] * p[:, 1] / p[:, 2] + K[1, 2]], 1)
+        assert ((uv[:, 0] > -50) & (uv[:, 0] < 1074) & (uv[:, 1] > -50) & (uv[:, 1] < 818)).mean() > 0.98
