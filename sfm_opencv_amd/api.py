@@ -423,3 +423,23 @@ def bundle_adjustment(intrinsic, extrinsics, correspond_struct_idx, key_points_f
               % (len(extrinsics), s["num_residuals"], np.sqrt(s["initial_cost"] / max(1, s["num_residuals"])),
                  np.sqrt(s["final_cost"] / max(1, s["num_residuals"])), s["total_time_s"]))
     return s
+
+
+def refine_structure(intrinsic, extrinsics, obs_cam, obs_pt, obs_uv, structure, max_px=4.0, ctx=None, opts=None):
+    """Extension (not reference behaviour, which never filters or re-triangulates: NViewReconstuct.cpp:1428-1453):
+    drop observations whose reprojection error exceeds max_px, re-triangulate every track from all its remaining observations
+    (sfmhip_triangulate_tracks), drop tracks left with fewer than two views, bundle-adjust again.
+    Returns (K4, ext, pts (kept), kept point ids, kept observation mask, summary)."""
+    ctx = ctx or default_context()
+    K4 = np.array(intrinsic, np.float64).reshape(4); ext = np.array(extrinsics, np.float64).reshape(-1, 6)
+    pts = np.array(structure, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32); uv = np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2)
+    err = ctx.reprojection_errors(K4, ext, pts, oc, op, uv)
+    keep = err <= max_px
+    new_pts, nv = ctx.triangulate_tracks(K4, ext, oc[keep], op[keep], uv[keep], len(pts))
+    ok = (nv >= 2) & np.isfinite(new_pts).all(1)
+    ids = np.nonzero(ok)[0]
+    remap = np.full(len(pts), -1, np.int64); remap[ids] = np.arange(len(ids))
+    keep &= ok[op]
+    K2, ext2, pts2, s = ctx.ba_solve(K4, ext, new_pts[ids], oc[keep], remap[op[keep]].astype(np.int32), uv[keep], opts)
+    return K2, ext2, pts2, ids, keep, s

@@ -950,6 +950,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
                      const sfm_ba_options* opts, sfmhip_ba** out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_ba_create");
     SFM_ARG_CHECK(ctx, ctx && out && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0);
     SFM_ARG_CHECK(ctx, (pts || n_pt == 0) && ((obs_cam && obs_pt && obs_uv) || n_obs == 0));
     for (int k = 0; k < n_obs; ++k)
@@ -1119,6 +1120,7 @@ int sfmhip_ba_reset(sfmhip_ba* h)
 int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 {
     SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
+    SFM_RANGE("sfmhip_ba_run");
     if (!h) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     h->started = false; h->built = false; h->cleared = false; h->campre_valid = false; h->top_cleared = false;
@@ -1130,6 +1132,7 @@ int sfmhip_ba_run(sfmhip_ba* h, sfm_ba_summary* summary)
 int sfmhip_ba_iterate(sfmhip_ba* h, int n_iter, sfm_ba_summary* summary)
 {
     SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
+    SFM_RANGE("sfmhip_ba_iterate");
     if (!h || n_iter < 0) return SFMHIP_E_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     for (double& v : h->phase_acc) v = 0; h->phase_cnt = 0;
@@ -1158,6 +1161,7 @@ int sfmhip_ba_get_params(sfmhip_ba* h, double* K4, double* ext6, double* pts)
 int sfmhip_ba_reduced_system(sfmhip_ba* h, double radius, double* S, double* rhs, int* n, double* cost)
 {
     SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
+    SFM_RANGE("sfmhip_ba_reduced_system");
     if (!h) return SFMHIP_E_ARG;
     sfmhip_ctx* ctx = h->ctx;
     if (n) *n = h->n;
@@ -1195,6 +1199,7 @@ int sfmhip_ba_solve(sfmhip_ctx* ctx, double* K4, double* ext6, int n_cam, double
                     const sfm_ba_options* opts, sfm_ba_summary* summary)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_ba_solve");
     sfmhip_ba* h = nullptr;
     int rc = sfmhip_ba_create(ctx, K4, ext6, n_cam, pts, n_pt, obs_cam, obs_pt, obs_uv, n_obs, opts, &h);
     if (rc) return rc;

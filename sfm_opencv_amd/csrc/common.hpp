@@ -43,6 +43,23 @@ struct SfmDeviceGuard {
 };
 #define SFM_DEVICE_GUARD(ctx) SfmDeviceGuard _sfm_device_guard(ctx)
 
+// roctx ranges around the C-ABI calls (tracing): visible in `rocprofv3 --marker-trace`.  The marker library is
+// looked up at run time (librocprofiler-sdk-roctx, else libroctx64); without it the ranges are no-ops, so libsfmhip.so keeps
+// its single dependency on the HIP runtime.
+struct SfmRoctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    SfmRoctx();
+    static const SfmRoctx& get() { static const SfmRoctx r; return r; }
+};
+struct SfmRange {
+    bool on;
+    explicit SfmRange(const char* name) : on(SfmRoctx::get().push != nullptr) { if (on) (void)SfmRoctx::get().push(name); }
+    ~SfmRange() { if (on) (void)SfmRoctx::get().pop(); }
+    SfmRange(const SfmRange&) = delete;
+    SfmRange& operator=(const SfmRange&) = delete;
+};
+#define SFM_RANGE(name) SfmRange _sfm_range(name)
+
 #define SFM_HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

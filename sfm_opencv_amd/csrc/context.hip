@@ -1,6 +1,19 @@
 // context.hip -- context lifetime + the host-only ratio tail of libsfmhip.so.
 #include "common.hpp"
 #include <cfloat>
+#include <dlfcn.h>
+
+SfmRoctx::SfmRoctx()
+{
+    for (const char* lib : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+        void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) continue;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+    }
+}
 
 extern "C" {
 

@@ -925,6 +925,7 @@ int sfmhip_descset_refresh(sfmhip_descset* s)
 int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_descsets_refresh");
     SFM_ARG_CHECK(ctx, ctx && (sets || n == 0) && n >= 0);
     std::vector<PrepDesc> tbl;
     int max_pad = 0;
@@ -1103,6 +1104,7 @@ int sfmhip_knn2_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, const sfmhip_d
                     int32_t* d_idx2, float* d_dist2, int force_path)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_knn2_dev");
     SFM_ARG_CHECK(ctx, ctx && query && train && d_idx2 && d_dist2);
     sfmhip_descset* sets[2] = { (sfmhip_descset*)query, (sfmhip_descset*)train };
     const int32_t pr[2] = { 0, 1 };
@@ -1117,6 +1119,7 @@ int sfmhip_match_pairs_dev(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_s
                            sfm_dmatch* d_matches, int max_per_pair, int32_t* d_counts)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_match_pairs_dev");
     SFM_ARG_CHECK(ctx, ctx && d_matches && d_counts && max_per_pair > 0);
     if (n_pairs == 0) return SFMHIP_OK;
     KnnPlan P; KnnWork W;
@@ -1139,6 +1142,7 @@ int sfmhip_match_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets,
                        sfm_dmatch* matches_out, int max_per_pair, int32_t* counts_out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_match_pairs");
     SFM_ARG_CHECK(ctx, ctx && matches_out && counts_out && max_per_pair > 0 && n_pairs >= 0);
     if (n_pairs == 0) return SFMHIP_OK;
     sfm_dmatch* d_m = nullptr; int32_t* d_c = nullptr;
@@ -1182,6 +1186,7 @@ int sfmhip_knn2_l2_f32(sfmhip_ctx* ctx, const float* q, int nq, const float* t, 
                        size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_knn2_l2_f32");
     SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
@@ -1195,6 +1200,7 @@ int sfmhip_knn2_hamming2_u8(sfmhip_ctx* ctx, const uint8_t* q, int nq, const uin
                             size_t ldq, size_t ldt, int32_t* idx2, float* dist2)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_knn2_hamming2_u8");
     SFM_ARG_CHECK(ctx, ctx && idx2 && dist2 && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
@@ -1220,6 +1226,7 @@ int sfmhip_match_features_l2(sfmhip_ctx* ctx, const float* q, int nq, const floa
                              size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_match_features_l2");
     SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_l2_host(ctx, q, nq, dim, ldq, &qs); if (rc) return rc;
@@ -1233,6 +1240,7 @@ int sfmhip_match_features_hamming2(sfmhip_ctx* ctx, const uint8_t* q, int nq, co
                                    size_t ldq, size_t ldt, sfm_dmatch* out, int* n_out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_match_features_hamming2");
     SFM_ARG_CHECK(ctx, ctx && out && n_out && nq >= 0 && nt >= 0);
     sfmhip_descset *qs = nullptr, *ts = nullptr;
     int rc = sfmhip_descset_create_hamming2_host(ctx, q, nq, nbytes, ldq, &qs); if (rc) return rc;
@@ -1262,6 +1270,7 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
                                   float* d_dist, size_t ld, int force_path)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_l2_distance_matrix_dev");
     SFM_ARG_CHECK(ctx, ctx && query && train && d_dist);
     SFM_ARG_CHECK(ctx, query->kind == SFMHIP_DESC_L2_F32 && train->kind == SFMHIP_DESC_L2_F32 && query->dim == train->dim);
     SFM_ARG_CHECK(ctx, ld >= (size_t)train->rows);

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NTILE) void normals_kernel(const double* __restrict
 extern "C" int sfmhip_estimate_normals(sfmhip_ctx* ctx, const double* pts, int n, int K, double* normals)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_estimate_normals");
     SFM_ARG_CHECK(ctx, ctx && n >= 0 && K >= 1 && K <= KMAX);
     if (n == 0) return SFMHIP_OK;
     SFM_ARG_CHECK(ctx, pts && normals);

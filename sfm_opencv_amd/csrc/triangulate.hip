@@ -189,6 +189,7 @@ int sfmhip_triangulate2_f32_dev(sfmhip_ctx* ctx, const float P1[12], const float
                                 const float* d_xy1, const float* d_xy2, int n, float* d_xyzw, double* d_xyz)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_triangulate2_f32_dev");
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && n >= 0);
     if (n == 0) return SFMHIP_OK;
     SFM_ARG_CHECK(ctx, d_xy1 && d_xy2 && (d_xyzw || d_xyz));
@@ -204,6 +205,7 @@ int sfmhip_triangulate2_matches_dev(sfmhip_ctx* ctx, const float P1[12], const f
                                     const sfm_dmatch* d_matches, int n, float* d_xyzw, double* d_xyz)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_triangulate2_matches_dev");
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && n >= 0);
     if (n == 0) return SFMHIP_OK;
     SFM_ARG_CHECK(ctx, d_kp1 && d_kp2 && d_matches && (d_xyzw || d_xyz));
@@ -220,6 +222,7 @@ int sfmhip_triangulate2_f32(sfmhip_ctx* ctx, const float P1[12], const float P2[
                             const float* xy1, const float* xy2, int n, float* xyzw, double* xyz)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_triangulate2_f32");
     SFM_ARG_CHECK(ctx, ctx && P1 && P2 && xy1 && xy2 && n > 0 && (xyzw || xyz));
     float *d1 = nullptr, *d2 = nullptr, *dw = nullptr; double* dx = nullptr;
     int rc = SFMHIP_OK;
@@ -244,6 +247,7 @@ int sfmhip_triangulate_tracks(sfmhip_ctx* ctx, const double K4[4], const double*
                               double* pts_out, int32_t* n_views_out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_triangulate_tracks");
     SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (pts_out || n_pt == 0));
     SFM_ARG_CHECK(ctx, (obs_cam && obs_pt && obs_uv) || n_obs == 0);
     for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);
@@ -282,6 +286,7 @@ int sfmhip_reprojection_errors(sfmhip_ctx* ctx, const double K4[4], const double
                                const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs, double* err_out)
 {
     SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_reprojection_errors");
     SFM_ARG_CHECK(ctx, ctx && K4 && ext6 && n_cam > 0 && n_pt >= 0 && n_obs >= 0 && (err_out || n_obs == 0));
     SFM_ARG_CHECK(ctx, n_obs == 0 || (pts && obs_cam && obs_pt && obs_uv));
     for (int k = 0; k < n_obs; ++k) SFM_ARG_CHECK(ctx, obs_cam[k] >= 0 && obs_cam[k] < n_cam && obs_pt[k] >= 0 && obs_pt[k] < n_pt);

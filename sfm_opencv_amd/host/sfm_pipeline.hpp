@@ -162,6 +162,59 @@ inline int init_structure(const Mat& K, const std::vector<std::vector<KeyPoint>>
     return 0;
 }
 
+// Extension (NOT reference behaviour: the reference triangulates a point once, from the pair that created it,
+// and never filters the matches of later pairs, NView:1428-1453): after a bundle adjustment, drop the observations whose
+// reprojection error exceeds `max_px`, re-triangulate every track from ALL its remaining observations (N-view DLT on the
+// GPU), drop tracks left with fewer than two observations or behind a camera, and adjust again.  Returns the number of
+// observations removed, -1 on error.  correspond_struct_idx, structure and colors are compacted in place.
+inline int refine_structure(Mat& intrinsic, std::vector<Mat>& extrinsics, std::vector<std::vector<int>>& correspond_struct_idx,
+                            std::vector<std::vector<KeyPoint>>& key_points_for_all, std::vector<Point3d>& structure,
+                            std::vector<Vec3b>& colors, double max_px = 4.0)
+{
+    sfmhip_ctx* ctx = context();
+    if (!ctx || structure.empty()) return -1;
+    const int nc = (int)extrinsics.size(), np = (int)structure.size();
+    std::vector<double> ext((size_t)6 * nc);
+    for (int c = 0; c < nc; ++c) std::memcpy(&ext[6 * (size_t)c], extrinsics[c].ptr<double>(), 6 * sizeof(double));
+    std::vector<int32_t> oc, op; std::vector<double> uv; std::vector<std::pair<int, int>> where;
+    auto gather = [&]() {
+        oc.clear(); op.clear(); uv.clear(); where.clear();
+        for (int img = 0; img < nc && img < (int)correspond_struct_idx.size(); ++img)
+            for (size_t k = 0; k < correspond_struct_idx[img].size(); ++k) {
+                const int id = correspond_struct_idx[img][k];
+                if (id < 0) continue;
+                oc.push_back(img); op.push_back(id); where.push_back({ img, (int)k });
+                uv.push_back((double)key_points_for_all[img][k].pt.x); uv.push_back((double)key_points_for_all[img][k].pt.y);
+            }
+    };
+    gather();
+    std::vector<double> err(oc.size());
+    if (sfmhip_reprojection_errors(ctx, intrinsic.ptr<double>(), ext.data(), nc, &structure[0].x, np, oc.data(), op.data(), uv.data(), (int)oc.size(), err.data()) != SFMHIP_OK)
+        { printf("[Err]: refine_structure: %s\n", sfmhip_last_error(ctx)); return -1; }
+    int removed = 0;
+    for (size_t q = 0; q < err.size(); ++q)
+        if (!(err[q] <= max_px)) { correspond_struct_idx[where[q].first][where[q].second] = -1; ++removed; }
+    gather();
+    std::vector<double> pts((size_t)3 * np); std::vector<int32_t> nviews((size_t)np);
+    if (sfmhip_triangulate_tracks(ctx, intrinsic.ptr<double>(), ext.data(), nc, oc.data(), op.data(), uv.data(), (int)oc.size(), np, pts.data(), nviews.data()) != SFMHIP_OK)
+        { printf("[Err]: refine_structure: %s\n", sfmhip_last_error(ctx)); return -1; }
+    // keep tracks with >= 2 views and a finite position; compact
+    std::vector<int> new_id((size_t)np, -1);
+    std::vector<Point3d> kept; std::vector<Vec3b> kept_col;
+    for (int p = 0; p < np; ++p) {
+        const bool ok = nviews[p] >= 2 && std::isfinite(pts[3 * (size_t)p]) && std::isfinite(pts[3 * (size_t)p + 1]) && std::isfinite(pts[3 * (size_t)p + 2]);
+        if (!ok) continue;
+        new_id[p] = (int)kept.size();
+        kept.emplace_back(pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]);
+        if ((size_t)p < colors.size()) kept_col.push_back(colors[p]);
+    }
+    for (auto& v : correspond_struct_idx) for (int& id : v) if (id >= 0) { if (new_id[id] < 0) ++removed; id = new_id[id]; }
+    printf("refine_structure: %d observations dropped (> %.2f px or orphaned), %zu of %d points kept.\n", removed, max_px, kept.size(), np);
+    structure.swap(kept); colors.swap(kept_col);
+    bundle_adjustment(intrinsic, extrinsics, correspond_struct_idx, key_points_for_all, structure);
+    return removed;
+}
+
 struct PipelineOptions {
     std::string out_dir = "../Viewer";     // the reference's relative output paths (NView:1458, 1505, 1511)
     bool poses_from_file = false;          // skip find_transform / solvePnPRansac, take R, T of every frame from the features file
@@ -170,6 +223,7 @@ struct PipelineOptions {
     int max_features = 0;                  // directory input: keep the strongest N key points per image (0: all, like the reference)
     std::string save_features;             // directory input: also write the extracted features to this file
     bool features_only = false;            // ... and stop there
+    double refine_px = 0.0;                // > 0: after BA, refine_structure(max_px) + a second BA (extension, not reference behaviour)
 };
 
 // main() of NViewReconstuct.cpp from "match_features_for_all" on (NView:1369-1517)
@@ -242,7 +296,12 @@ inline int run_nview(Features& f, const PipelineOptions& opt)
     std::vector<std::vector<KeyPoint>> kpts_ba(kpts_for_all.begin(), kpts_for_all.begin() + inds_ba.size());
     auto pts3d_old = pts3d;
     bundle_adjustment(intrinsic, extrinsics, inds_ba, kpts_ba, pts3d);
-    if (opt.print_offsets)
+    if (opt.refine_px > 0.0) {
+        pts3d_old.clear();
+        refine_structure(intrinsic, extrinsics, inds_ba, kpts_ba, pts3d, colors, opt.refine_px);
+        for (size_t i = 0; i < inds_ba.size(); ++i) inds_2d_to_3d[i] = inds_ba[i];
+    }
+    if (opt.print_offsets && pts3d_old.size() == pts3d.size())
         for (size_t i = 0; i < pts3d.size(); ++i)
             printf("Point3d %zu offset: [%.17g, %.17g, %.17g]\n", i, pts3d[i].x - pts3d_old[i].x, pts3d[i].y - pts3d_old[i].y, pts3d[i].z - pts3d_old[i].z);
 
@@ -299,7 +358,7 @@ inline int run_twoview(Features& f, const PipelineOptions& opt)
 inline int driver_main(int argc, char** argv, bool nview)
 {
     if (argc < 2 || std::string(argv[1]).empty()) {
-        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.ppm) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only]\n", argv[0]);
+        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.ppm) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
         return 0;
     }
     PipelineOptions opt;
@@ -311,6 +370,8 @@ inline int driver_main(int argc, char** argv, bool nview)
         else if (a == "--quiet") opt.print_offsets = false;
         else if (a == "--features-only") opt.features_only = true;
         else if (a.rfind("--max-features=", 0) == 0) opt.max_features = std::atoi(a.c_str() + 15);
+        else if (a == "--refine") opt.refine_px = 4.0;
+        else if (a.rfind("--refine=", 0) == 0) opt.refine_px = std::atof(a.c_str() + 9);
         else if (a.rfind("--save-features=", 0) == 0) opt.save_features = a.substr(16);
         else if (positional++ == 0) opt.out_dir = a;
     }

@@ -79,3 +79,22 @@ def test_nview_tracks_and_reprojection_errors_match_oracle(ctx):
     # ragged input: a point with a single observation and one with none
     p2, n2 = ctx.triangulate_tracks(sc["K_true"], sc["ext_true"], sc["obs_cam"][:1], np.zeros(1, np.int32), sc["obs_uv"][:1], 2)
     assert np.isnan(p2).all() and list(n2) == [1, 0]
+
+
+def test_refine_structure_filters_outliers_and_retriangulates(ctx):
+    """Extension: BA -> drop observations above 4 px -> N-view re-triangulation -> BA.  On a scene with 2 % gross
+    outliers (+-50 px) the filter removes (nearly) exactly those observations and the second BA reaches the noise floor."""
+    sc = synth.ba_scene(14, 2500, outlier_frac=0.02)
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    K, ext, pts, s = ctx.ba_solve(*args)
+    clean_uv = synth.project(sc["K_true"], sc["ext_true"][sc["obs_cam"]], sc["pts_true"][sc["obs_pt"]])
+    is_out = np.linalg.norm(sc["obs_uv"] - clean_uv, axis=1) > 6.0
+    assert 0.01 < is_out.mean() < 0.03
+    K2, ext2, pts2, ids, keep, s2 = api.refine_structure(K, ext, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], pts, max_px=4.0, ctx=ctx)
+    assert (~keep[is_out]).mean() > 0.97                      # the gross outliers are gone ...
+    assert keep[~is_out].mean() > 0.98                        # ... and hardly anything else
+    rm1 = np.sqrt(s["final_cost"] / s["num_residuals"]); rm2 = np.sqrt(s2["final_cost"] / s2["num_residuals"])
+    assert rm2 < rm1 and rm2 < 0.4                            # 0.5 px noise per axis: cost = sum r^2 / 2 -> rmse ~ 0.35
+    assert len(ids) > 0.98 * sc["n_pt"] and pts2.shape == (len(ids), 3)
+    e1 = np.linalg.norm(pts[ids] - sc["pts_true"][ids], axis=1); e2 = np.linalg.norm(pts2 - sc["pts_true"][ids], axis=1)
+    assert np.median(e2) <= np.median(e1) * 1.05
