@@ -52,6 +52,11 @@ int main()
         for (int m = 0; m < 32; ++m) { a += r[i * 32 + m] * r[j * 32 + m]; b += r[i * 32 + m] * r[1024 + m * 32 + j]; }
         e1 = fmax(e1, fabs(a - h[i * 32 + j])); e2 = fmax(e2, fabs(b - (i == j)));
     }
+#ifdef SFM_CHOL_STAMPS
+    { long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chol_stamps), sizeof st);
+      printf("stamps (cycles): panel0 init %lld pivots %lld tail %lld | panel1 init+cross %lld pivots %lld tail %lld | final %lld | total %lld\n",
+             st[1] - st[0], st[2] - st[1], st[4] - st[2], st[5] - st[4], st[6] - st[5], st[8] - st[6], st[9] - st[8], st[9] - st[0]); }
+#endif
     printf("ok flag %g  max|LL'-A| = %.3e  max|L Z - I| = %.3e  L[5][3]=%.6f Z[5][3]=%.6f upper L[3][5]=%g\n", r[4096], e1, e2, r[5 * 32 + 3], r[1024 + 5 * 32 + 3], r[3 * 32 + 5]);
     return 0;
 }

@@ -62,6 +62,7 @@ struct DiagLds {
     // one COLUMN per row: W[32 + c][m] = (L^-1)[m][c] -- i.e. read as a 32x32 array it is (L^-1)', the operand X = B (L^-1)' needs.
     double W[2 * SNB][SNB + 2];
     double G[2 * SNB][SPW + 2];         // one panel of the cross-panel update, handed from the MFMA result layout to lane = row
+    double Lc[SPW][2 * SNB];            // the panel's finished columns, one per row: broadcast source of the deferred rank-1 updates
 };
 // ---- multi-level nested dissection of the camera chain ---------------------------------------------------------------
 // The camera chain is cut into P = 2^m leaf segments by P - 1 separators of `w` cameras (w = band width of the camera
@@ -140,6 +141,12 @@ __device__ __forceinline__ void global_add_f64(double* p, double v)
     (void)__builtin_amdgcn_global_atomic_fadd_f64((global_f64*)p, v);
 }
 
+#ifdef SFM_CHOL_STAMPS
+__device__ long long g_chol_stamps[16];
+#define CSTAMP(i) do { if (lane == 0) g_chol_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 {
     const bool lower = lane < SNB;
@@ -151,6 +158,7 @@ __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
     for (int b = 0; b < SNB / SPW; ++b) {
         const int p = SPW * b;
         double x[SPW];
+        CSTAMP(4 * b + 0);
 #pragma unroll
         for (int c = 0; c < SPW; ++c) x[c] = lower ? dr[p + c] : (ident == p + c ? 1.0 : 0.0);
         if (b > 0) {
@@ -179,32 +187,59 @@ __device__ __forceinline__ bool wave_chol32(DiagLds& s, int lane)
 #pragma unroll
             for (int c = 0; c < SPW; c += 2) { const v2d t = *(const v2d*)&s.G[lane][c]; x[c] -= t.x; x[c + 1] -= t.y; }
         }
+        CSTAMP(4 * b + 1);
+        // Pivot steps.  Only the NEXT column takes its rank-1 update through v_readlane (it is on the dependent chain); the
+        // columns beyond get column j's update one step late, from an LDS broadcast of the finished column (one uniform-
+        // address ds_read per two values instead of four v_readlane_b32: 610 of the routine's 1,708 instructions were
+        // v_readlane), requested at the end of step j and consumed behind step j + 1's chain.
+        // Measured (experiments/chol_bench.hip, cycles per 32x32 block): 10.6k with per-column SPD tests and all updates
+        // through v_readlane; 9.6k with the single final test; 9.4k with the deferred updates (1,365 instructions).  Per
+        // 16-column panel the pivot loop is 2.7k cycles (166 per column), the cross-panel MFMA product + hand-over 1.6k, loads /
+        // stores / the final copy 2.7k.  No gain from: 2x2 block pivots (both reciprocal roots from one Newton latency:
+        // 9.7k), dealing the deferred updates out between the chain's operations with pinned order (10.5k), one 32-column
+        // panel (10.4k: the early steps become issue-bound).
+        double bv[SPW];                 // broadcast values of the column finished one step ago (requested at the end of that step)
 #pragma unroll
         for (int jj = 0; jj < SPW; ++jj) {
             const int j = p + jj;
             const double d = readlane_f64(x[jj], j);
-            ok = ok && (d > 0.0) && (d < 1e300);            // d <= 0: NaNs from here on, the caller rejects the factor
-            const double y = rsqrt_refined(d);
+            const double y = rsqrt_refined(d);              // d <= 0, NaN or inf: l_jj and everything after it turns NaN, caught by the one test at the end
             const double l = x[jj] * y;                     // lane j: d / sqrt(d)
             x[jj] = l;
+            if (jj + 1 < SPW) x[jj + 1] = fma(-l, readlane_f64(l, j + 1), x[jj + 1]);
+            if (jj + 2 < SPW) s.Lc[jj][lane] = l;
+            __builtin_amdgcn_sched_barrier(0);              // the deferred updates stay BEHIND the chain: their LDS reads have had a whole step to land
+            if (jj >= 1) {
 #pragma unroll
-            for (int c = jj + 1; c < SPW; ++c) x[c] = fma(-l, readlane_f64(l, p + c), x[c]);
+                for (int c = jj + 1; c < SPW; ++c) x[c] = fma(-x[jj - 1], bv[c], x[c]);
+            }
+            wave_sync_lds();
+            if (jj + 2 < SPW) {
+#pragma unroll
+                for (int c = jj + 2; c < SPW; ++c) bv[c] = s.Lc[jj][p + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        CSTAMP(4 * b + 2);
         // above the diagonal of L (upper half-wave: lane >= 32 > j): zero, off the pivot chain
 #pragma unroll
         for (int c = 0; c < SPW; ++c) x[c] = (lane < p + c) ? 0.0 : x[c];
 #pragma unroll
         for (int c = 0; c < SPW; c += 2) *(v2d*)&s.W[lane][p + c] = v2d{ x[c], x[c + 1] };
+        if (lower) {                    // the factor itself goes straight to s.D (odd row stride: 8-byte stores); a copy W -> D at the end cost 0.7k cycles
+#pragma unroll
+            for (int c = 0; c < SPW; ++c) s.D[lane][p + c] = x[c];
+        }
         wave_sync_lds();
     }
-    if (lower) {
-        v2d t[SNB / 2];                 // all reads first: interleaved with the stores the compiler waits after every one
-        const double* wr = &s.W[lane][0];
-#pragma unroll
-        for (int c = 0; c < SNB / 2; ++c) t[c] = *(const v2d*)(wr + 2 * c);
-#pragma unroll
-        for (int c = 0; c < SNB / 2; ++c) { s.D[lane][2 * c] = t[c].x; s.D[lane][2 * c + 1] = t[c].y; }
+    CSTAMP(8);
+    // positive-definiteness: one test of the finished diagonal instead of two compares per pivot step on the issue-bound
+    // chain (a failed pivot poisons its own diagonal entry and every later column with NaN)
+    {
+        const double dg = s.W[lane & (SNB - 1)][lane & (SNB - 1)];
+        ok = __builtin_amdgcn_ballot_w64(lower && !((dg > 0.0) && (dg < 1e150))) == 0ull;
     }
+    CSTAMP(9);
     return ok;
 }
 
