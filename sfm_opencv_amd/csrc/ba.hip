@@ -379,6 +379,8 @@ static int enqueue_solve(sfmhip_ba* h)
                     fprintf(stderr, "[stamps] panel %3d: stage %6lld | solve %6lld | next pivot %6lld | factor (wave 0) %6lld | trailing tiles %6lld + rhs %6lld (wave 1) | join %6lld   cycles\n", k,
                             hs[16 * k + 1] - hs[16 * k + 0], hs[16 * k + 4] - hs[16 * k + 1], hs[16 * k + 5] - hs[16 * k + 4],
                             hs[16 * k + 2] - hs[16 * k + 5], hs[16 * k + 7] - hs[16 * k + 5], hs[16 * k + 3] - hs[16 * k + 7], hs[16 * k + 6] - hs[16 * k + 2]);
+                    if (hs[16 * k + 8]) fprintf(stderr, "[stamps]   node starting at panel %d: descriptor %lld | assembly / damping %lld | panels %lld | total %lld cycles\n", k,
+                                                hs[16 * k + 9] - hs[16 * k + 8], hs[16 * k + 10] - hs[16 * k + 9], hs[16 * k + 11] - hs[16 * k + 10], hs[16 * k + 11] - hs[16 * k + 8]);
                     if (k + 1 < nb) fprintf(stderr, "[stamps]            to the next panel's start: %lld\n", hs[16 * (k + 1)] - hs[16 * k + 6]);
                 }
             }

@@ -571,59 +571,81 @@ __device__ __forceinline__ void damp_rows(double* __restrict__ A, int ld, const 
     }
 }
 
-// Assembly step of a node (see FoldEnt).  A thread owns one 16-byte element pair of every destination block; DB destinations
-// per batch with every load of the batch in flight before the first add (a dependent load from another workgroup's buffer
-// is a ~2 us round trip); sources are summed in list order (fixed => deterministic).  NSRC sources per destination are
-// requested up front, longer lists continue one by one.
+// Assembly step of a node (see FoldEnt).  The node's entries are first copied to LDS by one coalesced burst (read through
+// the global table every field is a dependent ~2 us round trip, and hipcc re-reads them after each store: the pass took
+// 27-43k cycles that way).  Then a thread owns one 16-byte element pair of every destination block; DB destinations per
+// batch with every load of the batch in flight before the first add; sources are summed in list order (fixed =>
+// deterministic).  NSRC sources per destination are requested up front, longer lists continue one by one.
+#define SFOLD_LDS 28        // entries staged in LDS per pass (a separator has ~14 + 4 right-hand-side pieces, the top ~10 + 4): 12 blocks + 16 pieces
 template <int DB, int NSRC>
-__device__ __forceinline__ void fold_node(const FoldEnt* __restrict__ ents, int e0, int e1, int e2, const SolverPlan& pl)
+__device__ __forceinline__ void fold_node(FoldEnt* __restrict__ sE, const FoldEnt* __restrict__ ents, int e0, int e1, int e2, const SolverPlan& pl)
 {
     const int tid = threadIdx.x;
     const int r = tid >> 4, c = (tid & 15) * 2;
-    for (int d0 = e0; d0 < e1; d0 += DB) {
-        v2d acc[DB], t[DB][NSRC];
-        double dmp[DB]; int msk[DB];
+    for (int base = e0; base < e2; base += SFOLD_LDS) {
+        const int cnt = e2 - base < SFOLD_LDS ? e2 - base : SFOLD_LDS;
+        __syncthreads();
+        {   // sizeof(FoldEnt) is a multiple of 8
+            const long long* src = (const long long*)(ents + base);
+            long long* dst = (long long*)sE;
+            for (int i = tid; i < cnt * (int)(sizeof(FoldEnt) / 8); i += STHREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+        const int nb_blk = e1 - base < cnt ? (e1 - base > 0 ? e1 - base : 0) : cnt;       // block entries in this pass: [0, nb_blk), right-hand-side entries after them
+        // right-hand-side entries: one thread per (destination, element) -- up to 16 destinations; their loads are issued
+        // together with the first batch of blocks
+        const int rdi = nb_blk + (tid >> 5), re = tid & 31;
+        const bool rhs_mine = rdi < cnt;
+        double rv = 0.0, rq[NSRC];
+        if (rhs_mine) {
+            const FoldEnt& E = sE[rdi];
+            rv = E.dst[re];
 #pragma unroll
-        for (int u = 0; u < DB; ++u)
-            if (d0 + u < e1) {
-                const FoldEnt& E = ents[d0 + u];
-                acc[u] = *(const v2d*)(E.dst + (size_t)r * E.dst_ld + c);
+            for (int q = 0; q < NSRC; ++q)
+                if (q < E.nsrc) rq[q] = E.src[q][re];
+        }
+        for (int d0 = 0; d0 < nb_blk || d0 == 0; d0 += DB) {
+            v2d acc[DB], t[DB][NSRC];
+            double dmp[DB]; int msk[DB];
 #pragma unroll
-                for (int q = 0; q < NSRC; ++q)
-                    if (q < E.nsrc) t[u][q] = *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
-                dmp[u] = 0.0; msk[u] = 1;
-                if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) { dmp[u] = pl.damp_diagU[E.diag0 + r]; msk[u] = pl.damp_mask[E.diag0 + r]; }
-            }
+            for (int u = 0; u < DB; ++u)
+                if (d0 + u < nb_blk) {
+                    const FoldEnt& E = sE[d0 + u];
+                    acc[u] = *(const v2d*)(E.dst + (size_t)r * E.dst_ld + c);
 #pragma unroll
-        for (int u = 0; u < DB; ++u)
-            if (d0 + u < e1) {
-                const FoldEnt& E = ents[d0 + u];
-#pragma unroll
-                for (int q = 0; q < NSRC; ++q)
-                    if (q < E.nsrc) acc[u] += t[u][q];
-                for (int q = NSRC; q < E.nsrc; ++q) acc[u] += *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
-                if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) {      // this thread's pair holds the diagonal element (r, r)
-                    const double add = fmin(fmax(dmp[u], pl.damp_min), pl.damp_max) / pl.damp_radius;
-                    if (r & 1) acc[u].y = msk[u] ? acc[u].y + add : 1.0; else acc[u].x = msk[u] ? acc[u].x + add : 1.0;
+                    for (int q = 0; q < NSRC; ++q)
+                        if (q < E.nsrc) t[u][q] = *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
+                    dmp[u] = 0.0; msk[u] = 1;
+                    if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) { dmp[u] = pl.damp_diagU[E.diag0 + r]; msk[u] = pl.damp_mask[E.diag0 + r]; }
                 }
-                *(v2d*)(E.dst + (size_t)r * E.dst_ld + c) = acc[u];
+            if (d0 == 0 && rhs_mine) {
+                const FoldEnt& E = sE[rdi];
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q)
+                    if (q < E.nsrc) rv += rq[q];
+                for (int q = NSRC; q < E.nsrc; ++q) rv += E.src[q][re];
+                E.dst[re] = rv;
             }
-    }
-    // right-hand side: one thread per (destination, element), 16 destinations per batch
-    for (int d0 = e1; d0 < e2; d0 += STHREADS / SNB) {
-        const int di = d0 + (tid >> 5), e = tid & 31;
-        if (di < e2) {
-            const FoldEnt& E = ents[di];
-            double v = E.dst[e];
-            double tq[NSRC];
 #pragma unroll
-            for (int q = 0; q < NSRC; ++q)
-                if (q < E.nsrc) tq[q] = E.src[q][e];
+            for (int u = 0; u < DB; ++u)
+                if (d0 + u < nb_blk) {
+                    const FoldEnt& E = sE[d0 + u];
 #pragma unroll
-            for (int q = 0; q < NSRC; ++q)
-                if (q < E.nsrc) v += tq[q];
-            for (int q = NSRC; q < E.nsrc; ++q) v += E.src[q][e];
-            E.dst[e] = v;
+                    for (int q = 0; q < NSRC; ++q)
+                        if (q < E.nsrc) acc[u] += t[u][q];
+                    for (int q = NSRC; q < E.nsrc; ++q) acc[u] += *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
+                    if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) {      // this thread's pair holds the diagonal element (r, r)
+                        const double add = fmin(fmax(dmp[u], pl.damp_min), pl.damp_max) / pl.damp_radius;
+                        if (r & 1) acc[u].y = msk[u] ? acc[u].y + add : 1.0; else acc[u].x = msk[u] ? acc[u].x + add : 1.0;
+                    }
+                    *(v2d*)(E.dst + (size_t)r * E.dst_ld + c) = acc[u];
+                }
+        }
+        for (int di = rdi + STHREADS / SNB; di < cnt; di += STHREADS / SNB) {      // more than 16 right-hand-side pieces in one pass (not at these sizes)
+            const FoldEnt& E = sE[di];
+            double v = E.dst[re];
+            for (int q = 0; q < E.nsrc; ++q) v += E.src[q][re];
+            E.dst[re] = v;
         }
     }
 }
@@ -652,15 +674,22 @@ __global__ __launch_bounds__(STHREADS) void chol_node_forward_kernel(double* __r
                                                                      const FoldEnt* __restrict__ ents, int* __restrict__ err)
 {
     __shared__ SolverLds s;
+#define NSTAMP(i) do { if (pl.stamps && threadIdx.x == 0) pl.stamps[(size_t)nd.k0 * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    const long long t_in = pl.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const NodeDesc nd = nodes[first + blockIdx.x];
+    if (pl.stamps && threadIdx.x == 0) pl.stamps[(size_t)nd.k0 * 16 + 8] = t_in;
+    NSTAMP(9);
     if (threadIdx.x < SAMAX) s.Anc[threadIdx.x] = nd.anc[threadIdx.x];
     if (nd.e0 == nd.e2) damp_rows(A, ld, pl, nd.k0 * SNB, nd.k1 * SNB);       // a leaf: nothing to assemble, only the damping
-    else fold_node<8, 2>(ents, nd.e0, nd.e1, nd.e2, pl);                       // two children per separator
+    else fold_node<8, 2>((FoldEnt*)&s.B[0][0], ents, nd.e0, nd.e1, nd.e2, pl);  // two children per separator; the entries are staged in s.B (free until the panels start)
     __syncthreads();
+    NSTAMP(10);
     double* U = ubuf + nd.u_off;
     const int ldu = nd.na * SNB;
     const bool ok = forward_panels<true>(s, A, ld, nd.k0, nd.k1, pl, rhs, U, ldu, nd.na, U + (size_t)ldu * ldu);
     if (!ok && threadIdx.x == 0) *err = 2;
+    NSTAMP(11);
+#undef NSTAMP
 }
 
 // the top node (last separators + intrinsics): assemble, factor serially, solve, and its share of the back-substitution
@@ -672,7 +701,7 @@ __global__ __launch_bounds__(STHREADS) void chol_top_kernel(double* __restrict__
     const int tid = threadIdx.x;
     const NodeDesc nd = nodes[top_node];
     const int t0 = nd.k0 * SNB, ntop = (nd.k1 - nd.k0) * SNB;
-    fold_node<2, SFOLD_SRC>(ents, nd.e0, nd.e1, nd.e2, pl);       // up to 8 children (the nodes of the last parallel level)
+    fold_node<4, 4>((FoldEnt*)&s.B[0][0], ents, nd.e0, nd.e1, nd.e2, pl);       // four children at C4 (up to 8: the nodes of the last parallel level)
     __syncthreads();
     const bool ok = forward_panels<false>(s, A, ld, nd.k0, nd.k1, pl, rhs, nullptr, 0, 0, nullptr);
     if (!ok && tid == 0) *err = 2;
