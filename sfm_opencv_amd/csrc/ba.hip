@@ -672,8 +672,9 @@ static int build_solver_plan(sfmhip_ba* h)
                         FoldEnt E; memset(&E, 0, sizeof E);
                         E.diag0 = -1;
                         const long long key = v[i].key;
-                        if (key >= BIG) {                       // hand-on into this node's own update buffer
+                        if (key >= BIG) {                       // hand-on into this node's own update buffer (all zero at this point)
                             const long long q = key - BIG;
+                            E.diag0 = -2;
                             if (is_rhs) { E.dst = Ud + C.u_off + ldc * ldc + q * NB; E.dst_ld = 0; }
                             else { E.dst = Ud + C.u_off + (q / SAMAX) * NB * ldc + (q % SAMAX) * NB; E.dst_ld = (int)ldc; }
                         } else if (is_rhs) { E.dst = rhsd + key * NB; E.dst_ld = 0; }

@@ -89,7 +89,8 @@ struct NodeDesc {
 struct FoldEnt {
     double* dst; const double* src[SFOLD_SRC];
     int dst_ld, src_ld[SFOLD_SRC];
-    int nsrc, diag0;        // diag0 >= 0: dst is a diagonal block of S whose first row has this position (damping applies)
+    int nsrc, diag0;        // diag0 >= 0: dst is a diagonal block of S whose first row has this position (damping applies);
+                            // diag0 == -2: dst lies in this node's own update buffer, which is still all zero (not read)
 };
 
 struct SolverLds : DiagLds {
@@ -599,7 +600,7 @@ __device__ __forceinline__ void fold_node(FoldEnt* __restrict__ sE, const FoldEn
         double rv = 0.0, rq[NSRC];
         if (rhs_mine) {
             const FoldEnt& E = sE[rdi];
-            rv = E.dst[re];
+            if (E.diag0 != -2) rv = E.dst[re];
 #pragma unroll
             for (int q = 0; q < NSRC; ++q)
                 if (q < E.nsrc) rq[q] = E.src[q][re];
@@ -611,7 +612,8 @@ __device__ __forceinline__ void fold_node(FoldEnt* __restrict__ sE, const FoldEn
             for (int u = 0; u < DB; ++u)
                 if (d0 + u < nb_blk) {
                     const FoldEnt& E = sE[d0 + u];
-                    acc[u] = *(const v2d*)(E.dst + (size_t)r * E.dst_ld + c);
+                    acc[u] = v2d{ 0.0, 0.0 };
+                    if (E.diag0 != -2) acc[u] = *(const v2d*)(E.dst + (size_t)r * E.dst_ld + c);
 #pragma unroll
                     for (int q = 0; q < NSRC; ++q)
                         if (q < E.nsrc) t[u][q] = *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
@@ -643,7 +645,7 @@ __device__ __forceinline__ void fold_node(FoldEnt* __restrict__ sE, const FoldEn
         }
         for (int di = rdi + STHREADS / SNB; di < cnt; di += STHREADS / SNB) {      // more than 16 right-hand-side pieces in one pass (not at these sizes)
             const FoldEnt& E = sE[di];
-            double v = E.dst[re];
+            double v = E.diag0 != -2 ? E.dst[re] : 0.0;
             for (int q = 0; q < E.nsrc; ++q) v += E.src[q][re];
             E.dst[re] = v;
         }
