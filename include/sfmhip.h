@@ -191,6 +191,9 @@ typedef struct {
     int    fix_first_camera;            /* 1    (NView:1178) */
     int    fix_intrinsics;              /* 0    (NView:1181: free, shared) */
     int    verbose;                     /* 0    (NView:1216-1217) */
+    int    linearizer;                  /* 0    how the reduced system is built (same result up to rounding): 0 / 1 = per-observation
+                                         *      kernels; 2 = run tiles (points sharing a camera list linearised once, reduced on the
+                                         *      matrix pipe) when every point has 1..7 observations, else the per-observation kernels */
 } sfm_ba_options;
 
 #define SFMHIP_BA_CONVERGENCE     0

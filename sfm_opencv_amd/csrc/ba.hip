@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "ba_kernels.hpp"
 #include "ba_solver.hpp"
+#include "ba_tiles.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -215,6 +216,13 @@ struct sfmhip_ba {
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
     bool force_dense = false;      // SFMHIP_EXPERIMENTS builds: SFMHIP_DENSE_SOLVER routes every problem to the dense fallback
     long long* d_stamps = nullptr; int stamp_calls = 0;      // SFMHIP_EXPERIMENTS builds only: per-panel cycle stamps of the solver
+    // run-tile linearisation (ba_tiles.hpp): segments of point runs, their tiles, and the fold table of ba_tile_reduce_kernel
+    bool use_tiles = false; int n_tseg = 0; long long n_ttiles = 0;
+    std::vector<TileSeg> tsegs; std::vector<int> tcams;
+    TileSeg* d_tsegs = nullptr; int* d_tcams = nullptr; double *d_tpart = nullptr, *d_tpart_seg = nullptr;
+    int *d_rd_start = nullptr, *d_rd_dst = nullptr, *d_rd_dst2 = nullptr; unsigned* d_rd_src = nullptr; int rd_nd = 0, rd_n_long = 0;
+    size_t rd_dst_cap = 0, rd_src_cap = 0;
+    std::vector<int> tile_tab_cam_pos; int tile_tab_npad = -1;      // the layout the fold table was built for
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
@@ -273,6 +281,8 @@ static int call_allreduce(sfmhip_ba* h, double* buf, size_t count)
     return SFMHIP_OK;
 }
 
+static int enqueue_build_exchange(sfmhip_ba* h);
+
 // linearise: message = [S | rhs | diagU | graw | scal] (undamped), summed over ranks.  at_candidate: at the candidate
 // parameters the last back-substitution produced (speculative build of the next iteration, see ba_loop).
 static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool timed)
@@ -293,6 +303,15 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     if (!at_candidate && !h->campre_valid) {
         hipLaunchKernelGGL(ba_campre_kernel, dim3(ceil_div(h->nc, 64)), dim3(64), 0, st, h->d_ext, h->nc, h->d_campre);
         h->campre_valid = true;
+    }
+    if (h->use_tiles) {
+        if (tv) { (void)hipEventRecord(tv[3], st); (void)hipEventRecord(tv[4], st); (void)hipEventRecord(tv[1], st); }
+        hipLaunchKernelGGL(ba_tile_kernel, dim3(h->n_tseg), dim3(256), TILE_LDS_BYTES, st, P, h->d_tsegs, h->d_tcams, h->d_tpart, h->d_tpart_seg, h->d_err);
+        if (tv) (void)hipEventRecord(tv[2], st);
+        hipLaunchKernelGGL(ba_tile_reduce_kernel, dim3(h->rd_n_long + ceil_div(h->rd_nd - h->rd_n_long, 256) + 1), dim3(256), 0, st, P, h->d_rd_start, h->d_rd_dst, h->d_rd_dst2, h->d_rd_src,
+                           h->rd_n_long, h->rd_nd, h->d_tpart, h->d_tpart_seg, h->n_tseg);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        return enqueue_build_exchange(h);
     }
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
     // The camera kernel and the Schur pair kernel both depend only on the point kernel and both leave issue slots idle, so
@@ -317,6 +336,14 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
             hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
     }
     SFM_HIP_TRY(ctx, hipGetLastError());
+    return enqueue_build_exchange(h);
+}
+
+// multi-rank: the packed sum of the reduced-system message over the ranks
+static int enqueue_build_exchange(sfmhip_ba* h)
+{
+    sfmhip_ctx* ctx = h->ctx;
+    hipStream_t st = ctx->stream;
     if (h->ar_fn) {
         const size_t np2 = (size_t)h->npad * h->npad, tail = h->msg_count - np2, count = (size_t)h->n_sblk * NB * NB + tail;
         const int tail_blocks = (int)std::min<size_t>((tail + 255) / 256, 64);
@@ -735,12 +762,113 @@ static int build_solver_plan(sfmhip_ba* h)
     return SFMHIP_E_ARG;
 }
 
+// Fold table of the run tiles for the current solver layout: for every entry of [S | rhs | diagU | graw] that the tiles
+// touch, the list of (+/-) tile elements that sum to it, segments in storage order.  With D_k the direct tile of
+// observation slot k (rows [E_ck (6) | E_K (4) | r]) and Z the (6M + 5)^2 product (rows [E_c0 .. E_cM-1 | E_K | r]):
+//   S[ck,ck] = sum D_k[c,c] - Z[ck,ck]     S[ck,cl] = -Z[ck,cl]     S[ck,K] = D_k[c,K] - Z[ck,K]     S[K,K] = sum_k D_k[K,K] - Z[K,K]
+//   rhs_ck = D_k[c,r] - Z[ck,r]     rhs_K = sum_k D_k[K,r] - Z[K,r]     diagU = diag D     graw = D[.,r]
+static int build_tile_tables(sfmhip_ba* h)
+{
+    if (!h->use_tiles) return SFMHIP_OK;
+    if (h->tile_tab_npad == h->npad && h->tile_tab_cam_pos == h->cam_pos) return SFMHIP_OK;
+    sfmhip_ctx* ctx = h->ctx;
+    const int ld = h->npad, koff = h->koff;
+    const long long np2 = (long long)ld * ld;
+    if (np2 + 3ll * ld >= (1ll << 31)) { ctx->last_error = "reduced system too large for the tile fold table"; return SFMHIP_E_ARG; }
+    std::vector<std::pair<int, unsigned>> ents;
+    ents.reserve((size_t)h->n_tseg * 600);
+    const unsigned NEG = 0x80000000u;
+    for (const TileSeg& sg : h->tsegs) {
+        const int M = sg.M;
+        int co[TILE_MMAX];
+        for (int k = 0; k < M; ++k) co[k] = h->cam_pos[h->tcams[sg.cams_off + k]];
+        auto D = [&](int k, int row, int col) -> unsigned { return (unsigned)((sg.tile_off + k) * 256 + tile_elem(row, col)); };
+        auto Z = [&](int a, int b) -> unsigned {
+            if (a < b) std::swap(a, b);
+            const int tr = a / 16, tc = b / 16;
+            return (unsigned)((sg.tile_off + M + tr * (tr + 1) / 2 + tc) * 256 + tile_elem(a % 16, b % 16));
+        };
+        auto sdst = [&](int r, int c) -> int { if (r < c) std::swap(r, c); return r * ld + c; };
+        for (int k = 0; k < M; ++k) {
+            if (co[k] < 0) continue;
+            for (int i = 0; i < 6; ++i) {
+                for (int j = 0; j <= i; ++j) { ents.push_back({ sdst(co[k] + i, co[k] + j), D(k, i, j) }); ents.push_back({ sdst(co[k] + i, co[k] + j), Z(6 * k + i, 6 * k + j) | NEG }); }
+                if (!h->fixK)
+                    for (int j = 0; j < 4; ++j) { ents.push_back({ sdst(co[k] + i, koff + j), D(k, i, 6 + j) }); ents.push_back({ sdst(co[k] + i, koff + j), Z(6 * k + i, 6 * M + j) | NEG }); }
+                ents.push_back({ (int)np2 + co[k] + i, D(k, i, 10) }); ents.push_back({ (int)np2 + co[k] + i, Z(6 * k + i, 6 * M + 4) | NEG });
+                ents.push_back({ (int)np2 + ld + co[k] + i, D(k, i, i) });
+                ents.push_back({ (int)np2 + 2 * ld + co[k] + i, D(k, i, 10) });
+            }
+            for (int l = 0; l < k; ++l) {
+                if (co[l] < 0) continue;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        ents.push_back({ sdst(co[k] + i, co[l] + j), Z(6 * k + i, 6 * l + j) | NEG });
+                        if (co[k] == co[l] && i == j) ents.push_back({ sdst(co[k] + i, co[l] + j), Z(6 * k + i, 6 * l + j) | NEG });     // one camera twice: block + its transpose
+                    }
+            }
+        }
+        if (!h->fixK) {
+            for (int i = 0; i < 4; ++i) {
+                for (int j = 0; j <= i; ++j) {
+                    for (int k = 0; k < M; ++k) ents.push_back({ sdst(koff + i, koff + j), D(k, 6 + i, 6 + j) });
+                    ents.push_back({ sdst(koff + i, koff + j), Z(6 * M + i, 6 * M + j) | NEG });
+                }
+                for (int k = 0; k < M; ++k) {
+                    ents.push_back({ (int)np2 + koff + i, D(k, 6 + i, 10) });
+                    ents.push_back({ (int)np2 + ld + koff + i, D(k, 6 + i, 6 + i) });
+                    ents.push_back({ (int)np2 + 2 * ld + koff + i, D(k, 6 + i, 10) });
+                }
+                ents.push_back({ (int)np2 + koff + i, Z(6 * M + i, 6 * M + 4) | NEG });
+            }
+        }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const std::pair<int, unsigned>& a, const std::pair<int, unsigned>& b) { return a.first < b.first; });
+    // destinations with long source lists first (a workgroup each in ba_tile_reduce_kernel), then the rest in ascending order
+    std::vector<int> start, dst, dst2; std::vector<unsigned> src; src.reserve(ents.size());
+    h->rd_n_long = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t e = 0; e < ents.size();) {
+            size_t f = e;
+            while (f < ents.size() && ents[f].first == ents[e].first) ++f;
+            if ((f - e > 192) == (pass == 0)) {
+                start.push_back((int)src.size()); dst.push_back(ents[e].first);
+                int m = -1;
+                if (ents[e].first < np2) { const int r = ents[e].first / ld, c = ents[e].first % ld; if (r != c) m = c * ld + r; }
+                dst2.push_back(m);
+                for (size_t g = e; g < f; ++g) src.push_back(ents[g].second);
+                if (pass == 0) ++h->rd_n_long;
+            }
+            e = f;
+        }
+    start.push_back((int)src.size());
+    h->rd_nd = (int)dst.size();
+    int rc = SFMHIP_OK;
+    if (dst.size() + 1 > h->rd_dst_cap) {
+        rc = dalloc(h, &h->d_rd_start, dst.size() + 1); if (rc) return rc;
+        rc = dalloc(h, &h->d_rd_dst, dst.size() + 1); if (rc) return rc;
+        rc = dalloc(h, &h->d_rd_dst2, dst.size() + 1); if (rc) return rc;
+        h->rd_dst_cap = dst.size() + 1;
+    }
+    if (src.size() + 1 > h->rd_src_cap) { rc = dalloc(h, &h->d_rd_src, src.size() + 1); if (rc) return rc; h->rd_src_cap = src.size() + 1; }
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_rd_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (!dst.empty()) {
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_rd_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_rd_dst2, dst2.data(), dst2.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (!src.empty()) SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_rd_src, src.data(), src.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    h->tile_tab_npad = h->npad; h->tile_tab_cam_pos = h->cam_pos;
+    return SFMHIP_OK;
+}
+
 // iteration 0 work: jacobi scaling from the column norms at x0, |x0|
 static int ba_start(sfmhip_ba* h)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     { int rc = build_solver_plan(h); if (rc) return rc; }
+    { int rc = build_tile_tables(h); if (rc) return rc; }
     const size_t np3 = 3 * (size_t)h->np;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->npad_max + 255) / 256)), dim3(256), 0, st, h->d_scale_c, (size_t)h->npad_max, 1.0);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((np3 + 255) / 256 + 1)), dim3(256), 0, st, h->d_scale_p, np3, 1.0);
@@ -929,6 +1057,7 @@ void sfmhip_ba_default_options(sfm_ba_options* o)
     o->fix_first_camera = 1;
     o->fix_intrinsics = 0;
     o->verbose = 0;
+    o->linearizer = 0;
 }
 
 void sfmhip_ba_destroy(sfmhip_ba* h)
@@ -999,6 +1128,10 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     for (int k = 0; k < n_obs; ++k) pt_start[slot[obs_pt[k]] + 1]++;
     for (int p = 0; p < n_pt; ++p) pt_start[p + 1] += pt_start[p];
     for (int k = 0; k < n_obs; ++k) { const int p = slot[obs_pt[k]]; perm[pt_start[p] + fill[p]++] = k; }
+    // a point's observations in ascending camera order: the k-th observation of every point of a run (points with the same
+    // camera list are neighbours) then belongs to the same camera, which is what the run tiles rely on
+    for (int p = 0; p < n_pt; ++p)
+        std::stable_sort(perm.begin() + pt_start[p], perm.begin() + pt_start[p + 1], [&](int a, int b) { return obs_cam[a] < obs_cam[b]; });
     for (int q = 0; q < n_obs; ++q) { const int k = perm[q]; ocam[q] = obs_cam[k]; opt[q] = slot[obs_pt[k]]; ouv[2 * (size_t)q] = obs_uv[2 * (size_t)k]; ouv[2 * (size_t)q + 1] = obs_uv[2 * (size_t)k + 1]; }
     std::vector<int> cam_start(n_cam + 1, 0), cam_pt(n_obs), cfill(n_cam, 0);
     std::vector<double> cam_uv(2 * (size_t)n_obs);
@@ -1050,6 +1183,41 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->n_diag_blk = 0;
     for (size_t b = 0; b + 1 < blk_cam.size(); b += 2) if (blk_cam[b] == blk_cam[b + 1]) ++h->n_diag_blk;
 
+    // ---- run tiles: runs of points with one camera list, cut into segments of <= seg_max points (one workgroup each)
+    {
+        int seg_max = 320;
+#ifdef SFMHIP_EXPERIMENTS
+        if (const char* e = getenv("SFMHIP_TILE_SEG")) seg_max = std::max(16, atoi(e));
+#endif
+        bool fits = n_pt > 0;
+        long long tiles = 0;
+        h->tsegs.clear(); h->tcams.clear();
+        for (int p = 0; p < n_pt && fits;) {
+            const int M = pt_start[p + 1] - pt_start[p];
+            if (M < 1 || M > TILE_MMAX) { fits = false; break; }
+            int q = p + 1;
+            while (q < n_pt && pt_start[q + 1] - pt_start[q] == M && std::equal(ocam.begin() + pt_start[p], ocam.begin() + pt_start[p + 1], ocam.begin() + pt_start[q])) ++q;
+            const int len = q - p, nseg = ceil_div(len, seg_max), per = round_up(ceil_div(len, nseg), 16);
+            const int cams_off = (int)h->tcams.size();
+            for (int k = 0; k < M; ++k) h->tcams.push_back(ocam[pt_start[p] + k]);
+            const int R = 6 * M + 5, T = (R + 15) / 16, NT = M + T * (T + 1) / 2;
+            for (int a = p; a < q; a += per) {
+                TileSeg sg; sg.p0 = a; sg.npts = std::min(per, q - a); sg.obs0 = pt_start[a]; sg.M = M; sg.cams_off = cams_off; sg.tile_off = (int)tiles; sg.pad0 = sg.pad1 = 0;
+                h->tsegs.push_back(sg); tiles += NT;
+            }
+            p = q;
+        }
+        // heaviest segments first (work per point grows with M: more tiles, and two observations per lane from M = 5): the
+        // dispatcher hands workgroups out in index order, so the short ones fill the tail
+        std::stable_sort(h->tsegs.begin(), h->tsegs.end(), [](const TileSeg& a, const TileSeg& b) { return a.M > b.M; });
+        if (tiles * 256 >= (1ll << 31)) fits = false;                // the fold table addresses the tile buffer with 31 bits
+        h->n_tseg = (int)h->tsegs.size(); h->n_ttiles = tiles;
+        // opt-in only: measured on MI355X the tile kernel + fold take 0.125 + 0.04 ms at C4 against 0.13 ms for the whole
+        // per-observation pipeline (profiles/README.md, round 2), so 0 = "choose" resolves to the per-observation kernels
+        h->use_tiles = fits && h->o.linearizer == 2;
+        if (!h->use_tiles) { h->tsegs.clear(); h->tcams.clear(); h->n_tseg = 0; h->n_ttiles = 0; }
+    }
+
     int rc = SFMHIP_OK;
 #define TRY_RC(x) do { rc = (x); if (rc) { sfmhip_ba_destroy(h); return rc; } } while (0)
     TRY_RC(dupload(h, &h->d_K, K4, 4)); TRY_RC(dupload(h, &h->d_ext, ext6, 6 * (size_t)n_cam)); TRY_RC(dupload(h, &h->d_pts, pts_s.data(), 3 * (size_t)n_pt));
@@ -1072,6 +1240,13 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_chunk, blk_chunk.data(), blk_chunk.size()));
     TRY_RC(dupload(h, &h->d_items, flat.data(), flat.size())); TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));
     TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));
+    if (h->use_tiles) {
+        TRY_RC(dupload(h, &h->d_tsegs, h->tsegs.data(), h->tsegs.size())); TRY_RC(dupload(h, &h->d_tcams, h->tcams.data(), h->tcams.size()));
+        TRY_RC(dalloc(h, &h->d_tpart, (size_t)h->n_ttiles * 256)); TRY_RC(dalloc(h, &h->d_tpart_seg, 2 * (size_t)h->n_tseg));
+        if (hipFuncSetAttribute((const void*)ba_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES) != hipSuccess) {
+            sfmhip_ba_destroy(h); ctx->last_error = "hipFuncSetAttribute(ba_tile_kernel)"; return SFMHIP_E_HIP;
+        }
+    }
     TRY_RC(dalloc(h, &h->d_scale_c, (size_t)h->npad_max)); TRY_RC(dalloc(h, &h->d_scale_p, 3 * (size_t)n_pt));
     TRY_RC(dalloc(h, &h->d_campre, CAMPRE * (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_campre_c, CAMPRE * (size_t)n_cam));
     TRY_RC(dalloc(h, &h->d_cam_pos, (size_t)n_cam)); TRY_RC(dalloc(h, &h->d_posmask, (size_t)h->npad_max));

@@ -326,3 +326,72 @@ def test_angle_axis_first_order_branch_and_tiny_angles(ctx, omega):
         pb.close()
         assert abs(cost - costo) <= 1e-12 * costo
         assert _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# linearizer = 2: the run-tile construction of the reduced system (csrc/ba_tiles.hpp) -- opt-in, same contract
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(huber_delta=0.0), dict(fix_intrinsics=1), dict(jacobi_scaling=0), dict(fix_first_camera=0)])
+def test_run_tiles_reduced_system_matches_oracle(ctx, kw):
+    # 12 cameras / 700 points: runs of ~12 points (partly filled 16-point batches); 40 / 9000: runs of ~50 (several batches per wave)
+    for shape in ((12, 700), (40, 9000)):
+        sc = synth.ba_scene(*shape)
+        for radius in (1e4, 3.0):
+            pb = ctx.ba_create(*_args(sc), opts=ctx.ba_options(linearizer=2, **kw))
+            S, rhs, cost = pb.reduced_system(radius)
+            So, rhso, costo = orc.ba_reduced_system(*_args(sc), radius, opts=orc.ba_default_options(**kw))
+            assert abs(cost - costo) <= 1e-12 * costo
+            assert np.abs(S - S.T).max() <= 1e-12 * np.abs(S).max()
+            assert _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9       # same tolerance as the per-observation kernels
+            pb.close()
+
+
+def test_run_tiles_duplicate_camera_single_obs_and_long_tracks(ctx):
+    sc = synth.ba_scene(9, 300, outlier_frac=0.0, max_len=7)
+    oc, op, uv = sc["obs_cam"].copy(), sc["obs_pt"].copy(), sc["obs_uv"].copy()
+    cnt = np.bincount(op)
+    assert cnt.max() == 7                               # 7 observations: three row tiles, two observations per lane
+    pa, pb_ = int(np.nonzero(cnt <= 5)[0][0]), int(np.nonzero(cnt >= 3)[0][1])
+    k = np.nonzero(op == pa)[0][0]                      # point pa seen twice by one camera, point pb_ seen once
+    oc = np.append(oc, oc[k]); op = np.append(op, pa); uv = np.vstack([uv, uv[k] + [0.7, -0.4]])
+    keep = np.ones(len(oc), bool); keep[np.nonzero(op == pb_)[0][1:]] = False
+    oc, op, uv = oc[keep], op[keep], uv[keep]
+    So, rhso, costo = orc.ba_reduced_system(sc["K0"], sc["ext0"], sc["pts0"], oc, op, uv, 100.0)
+    pb = ctx.ba_create(sc["K0"], sc["ext0"], sc["pts0"], oc, op, uv, opts=ctx.ba_options(linearizer=2))
+    S, rhs, cost = pb.reduced_system(100.0)
+    assert _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9 and abs(cost - costo) <= 1e-12 * costo
+    pb.close()
+    # a track longer than the tiles take (8 observations): the request falls back to the per-observation kernels
+    sc8 = synth.ba_scene(10, 200, min_len=8, max_len=8)
+    pb = ctx.ba_create(*_args(sc8), opts=ctx.ba_options(linearizer=2))
+    S, rhs, cost = pb.reduced_system(100.0)
+    So, rhso, costo = orc.ba_reduced_system(*_args(sc8), 100.0)
+    assert _relerr(S, So) <= 1e-9 and _relerr(rhs, rhso) <= 1e-9
+    pb.close()
+
+
+@pytest.mark.parametrize("shape", [(24, 4000), (120, 30000)])
+def test_run_tiles_iterations_follow_the_per_observation_path_and_repeat_bitwise(ctx, shape):
+    sc = synth.ba_scene(*shape)
+    ref = ctx.ba_create(*_args(sc)); sr = ref.iterate(6); Kr, extr, ptsr = ref.params(); ref.close()
+    outs = []
+    for _ in range(2):
+        pb = ctx.ba_create(*_args(sc), opts=ctx.ba_options(linearizer=2))
+        s = pb.iterate(6); outs.append(pb.params()); pb.close()
+        assert s["successful_steps"] == sr["successful_steps"]
+        assert abs(s["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+    K, ext, pts = outs[0]
+    assert np.abs(ext - extr).max() <= 1e-8 and np.abs(pts - ptsr).max() <= 1e-8 and np.abs(K - Kr).max() <= 1e-8 * np.abs(Kr).max()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)                     # fixed reduction orders: reruns are bit-identical
+
+
+def test_run_tiles_two_point_shards_match_unsharded(ctx):
+    sc = synth.ba_scene(24, 4000)
+    ref = ctx.ba_create(*_args(sc)); sr = ref.iterate(5); Kr, extr, ptsr = ref.params(); ref.close()
+    out, params, ids, counts = _run_sharded_on_one_gpu(sc, 5, opts_of_rank=lambda r: dict(linearizer=2))
+    for r in range(2):
+        assert out[r]["successful_steps"] == sr["successful_steps"]
+        assert abs(out[r]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        K, ext, pts = params[r]
+        assert np.abs(ext - extr).max() <= 1e-8 and np.abs(pts - ptsr[ids[r]]).max() <= 1e-8
