@@ -314,27 +314,16 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
         return enqueue_build_exchange(h);
     }
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
-    // The camera kernel and the Schur pair kernel both depend only on the point kernel and both leave issue slots idle, so
-    // they run side by side: the pair kernel on the auxiliary stream, followed there by the fold of its partials into the
-    // off-diagonal blocks of S (ba_schur_reduce_kernel is their only writer); the rare (a, a) blocks after the join.
-    if (h->nblk > 0) {
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
-        SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        if (tv) (void)hipEventRecord(tv[3], h->aux);
-        hipLaunchKernelGGL(ba_schur_kernel, dim3(round_up(ceil_div(h->nchunk, 4), 8)), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
-        if (tv) (void)hipEventRecord(tv[4], h->aux);
-        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, h->aux, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 0);
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
-    } else if (tv) { (void)hipEventRecord(tv[3], st); (void)hipEventRecord(tv[4], st); }
-    if (tv) (void)hipEventRecord(tv[1], st);
-    hipLaunchKernelGGL(ba_camera_kernel, dim3(round_up(h->nc * h->cam_split * (h->fixK ? 1 : 2), 8)), dim3(256), 0, st, P);
-    if (tv) (void)hipEventRecord(tv[2], st);
-    hipLaunchKernelGGL(ba_finalize_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks);
-    if (h->nblk > 0) {
-        SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
-        if (h->n_diag_blk > 0)
-            hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
-    }
+    // camera items and pair chunks in one launch, then their folds in one launch (ba_kernels.hpp: ba_camschur_kernel)
+    const int n_cam_blocks = round_up(h->nc * h->cam_split * (h->fixK ? 1 : 2), 8);
+    const int n_schur_blocks = h->nblk > 0 ? round_up(ceil_div(h->nchunk, 4), 8) : 0;
+    if (tv) { (void)hipEventRecord(tv[1], st); (void)hipEventRecord(tv[3], st); }
+    hipLaunchKernelGGL(ba_camschur_kernel, dim3(n_cam_blocks + n_schur_blocks), dim3(256), 0, st, P, n_cam_blocks, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+    if (tv) { (void)hipEventRecord(tv[2], st); (void)hipEventRecord(tv[4], st); }
+    hipLaunchKernelGGL(ba_fold_kernel, dim3(h->nc + 1 + (h->nblk > 0 ? ceil_div(h->nblk * 36, 256) : 0)), dim3(256), 0, st, P, h->n_pt_blocks,
+                       h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
+    if (h->n_diag_blk > 0)
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return enqueue_build_exchange(h);
 }

@@ -503,12 +503,13 @@ __host__ __device__ constexpr int cam_part_slot(int part, int j)
 // gives every XCD one contiguous range of items: consecutive cameras (and camera pairs) share most of their points, so
 // each XCD's L2 serves a point's record to all the observations of it instead of every observation fetching it over the
 // fabric (the linearisation moved ~0.5 GB per pass for 90 MB of distinct data and ran at the fabric's rate).
-__device__ __forceinline__ int xcd_item(int n_items, int plain)
+__device__ __forceinline__ int xcd_item_of(int L, int n_blocks, int n_items, int plain)      // n_blocks (and the first block of the range) multiples of 8
 {
-    const int L = blockIdx.x, per = (gridDim.x + 7) >> 3;           // gridDim.x is a multiple of 8
+    const int per = (n_blocks + 7) >> 3;
     const int v = plain ? L : (L & 7) * per + (L >> 3);
     return v < n_items ? v : -1;
 }
+__device__ __forceinline__ int xcd_item(int n_items, int plain) { return xcd_item_of(blockIdx.x, gridDim.x, n_items, plain); }
 
 template <int PART>
 __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAMACC], int c, int sp_i)
@@ -601,12 +602,12 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
     }
 }
 
-__global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
+// workgroup L of n_blocks: one (camera, slice, part) item
+__device__ __forceinline__ void ba_camera_role(const BADev& P, double (*red)[CAMACC], int L, int n_blocks)
 {
-    __shared__ double red[4][CAMACC];
     // item = (camera * cam_split + slice) * parts + part: the two parts of a slice sit next to each other
     const int parts = P.fixK ? 1 : 2;
-    const int v = xcd_item(P.nc * P.cam_split * parts, P.xcd_plain);
+    const int v = xcd_item_of(L, n_blocks, P.nc * P.cam_split * parts, P.xcd_plain);
     if (v < 0) return;
     const int part = v % parts, cs = v / parts, c = cs / P.cam_split, sp_i = cs % P.cam_split;
     if (part == 0) ba_camera_body<0>(P, red, c, sp_i); else ba_camera_body<1>(P, red, c, sp_i);
@@ -616,13 +617,13 @@ __global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
 // K_finalize: block c < nc sums camera c's split partials and writes its S blocks / rhs / diagU / graw;
 // block nc reduces the intrinsic terms: S_KK = sum_c UKK - sum_blocks SKK, rhs_K, cost, local gmax.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_blocks)
+__device__ __forceinline__ void ba_finalize_role(const BADev& P, int n_pt_blocks, int blk)
 {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
     const int ld = P.npad;
-    if ((int)blockIdx.x < P.nc) {
-        const int c = blockIdx.x, co = cam_off(P, c);
+    if (blk < P.nc) {
+        const int c = blk, co = cam_off(P, c);
         if (co < 0) return;
         if (tid < CAMACC) {
             double v = 0.0;
@@ -699,11 +700,11 @@ __global__ __launch_bounds__(256) void ba_finalize_kernel(BADev P, int n_pt_bloc
 // S_ab = S_ba' = -sum; a == b (one point seen twice by one camera) adds the symmetrised term onto the diagonal
 // block written by K_finalize.  chunk_desc: [ca, cb, first item, end item]; items: [obs i, obs j, point, -].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
-                                                       const int4* __restrict__ items, double* __restrict__ part)
+__device__ __forceinline__ void ba_schur_role(const BADev& P, const int4* __restrict__ chunk_desc, int n_chunk,
+                                              const int4* __restrict__ items, double* __restrict__ part, int L, int n_blocks)
 {
     const int lane = threadIdx.x & 63;
-    const int item = xcd_item((n_chunk + 3) >> 2, P.xcd_plain);                   // four consecutive chunks per workgroup
+    const int item = xcd_item_of(L, n_blocks, (n_chunk + 3) >> 2, P.xcd_plain);  // four consecutive chunks per workgroup
     if (item < 0) return;
     const int chunk = item * 4 + (threadIdx.x >> 6);
     if (chunk >= n_chunk) return;
@@ -762,10 +763,10 @@ __global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* _
 // diag_pass = 0: the off-diagonal blocks (the only writer of those: runs on the pair kernel's stream, beside K_cam and
 // K_finalize); diag_pass = 1: the a == b blocks, which add onto what K_finalize wrote (launched after the join, and only
 // when such blocks exist).
-__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
-                                                              int n_blk, const double* __restrict__ part, int diag_pass)
+__device__ __forceinline__ void ba_schur_reduce_role(const BADev& P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
+                                                     int n_blk, const double* __restrict__ part, int diag_pass, int wg)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = wg * 256 + threadIdx.x;
     const int blk = t / 36, e = t % 36;
     if (blk >= n_blk) return;
     const int ca = blk_cam[2 * blk], cb = blk_cam[2 * blk + 1];
@@ -781,6 +782,34 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int
     } else {
         P.S[(size_t)(oa + i) * ld + oa + j] -= sum + sumT;
     }
+}
+
+// The launches of the build after K_pt.  K_cam and K_schur depend only on K_pt and both leave issue slots idle, so their
+// workgroups share ONE launch (first n_cam_blocks: camera items, the rest: pair chunks; both counts multiples of 8, so a
+// workgroup's XCD is its role-local index mod 8) -- as two launches on two streams the fork / join events cost 5-7 us of stream
+// gap each.  Likewise the two folds: K_finalize's workgroups and the off-diagonal pass of K_schur_reduce write disjoint parts
+// of the message; the rare (a, a) blocks add onto what K_finalize wrote and keep their own launch (diag_pass = 1).
+__global__ __launch_bounds__(256, 3) void ba_camschur_kernel(BADev P, int n_cam_blocks, const int4* __restrict__ chunk_desc, int n_chunk,
+                                                          const int4* __restrict__ items, double* __restrict__ part)
+{
+    __shared__ double red[4][CAMACC];
+    // groups of 8 workgroups (one per XCD) alternate between the roles in proportion, so that both kinds are resident together
+    // from the first wave of dispatches to the last (camera items first, then pair chunks: 89 us; mixed: see profiles/README.md)
+    const int G = gridDim.x >> 3, Gc = n_cam_blocks >> 3, g = blockIdx.x >> 3;
+    const int before = (int)(((long long)g * Gc) / G), upto = (int)(((long long)(g + 1) * Gc) / G);      // camera groups in [0, g) and [0, g]
+    if (upto > before) ba_camera_role(P, red, before * 8 + (blockIdx.x & 7), n_cam_blocks);
+    else ba_schur_role(P, chunk_desc, n_chunk, items, part, (g - before) * 8 + (blockIdx.x & 7), gridDim.x - n_cam_blocks);
+}
+__global__ __launch_bounds__(256) void ba_fold_kernel(BADev P, int n_pt_blocks, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
+                                                      int n_blk, const double* __restrict__ part)
+{
+    if ((int)blockIdx.x <= P.nc) ba_finalize_role(P, n_pt_blocks, blockIdx.x);
+    else ba_schur_reduce_role(P, blk_cam, blk_chunk, n_blk, part, 0, blockIdx.x - (P.nc + 1));
+}
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev P, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
+                                                              int n_blk, const double* __restrict__ part, int diag_pass)
+{
+    ba_schur_reduce_role(P, blk_cam, blk_chunk, n_blk, part, diag_pass, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
