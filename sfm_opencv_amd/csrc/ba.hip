@@ -205,7 +205,6 @@ struct sfmhip_ba {
     hipEvent_t evb[2][5] = {};          // per build parity: [start, camera kernel begin/end, pair kernel begin/end]
     hipEvent_t evi[2][5] = {};          // per iteration parity: [damped, solved, back-substituted, forward kernel begin/end]
     int iter_parity = 0, pending_build = -1, pending_iter = -1;       // timings not yet read (read off the decision path)
-    hipEvent_t ev_scal = nullptr;       // the iteration's scalars have landed in pinned memory
     bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
     bool top_cleared = false;      // d_topbuf was zero-filled ahead of time (behind the publish kernel, while the host decides)
     int n_diag_blk = 0;            // camera pairs (a, a): a point seen twice by one camera
@@ -217,6 +216,7 @@ struct sfmhip_ba {
     bool force_dense = false;      // SFMHIP_EXPERIMENTS builds: SFMHIP_DENSE_SOLVER routes every problem to the dense fallback
     long long* d_stamps = nullptr; int stamp_calls = 0;      // SFMHIP_EXPERIMENTS builds only: per-panel cycle stamps of the solver
     // run-tile linearisation (ba_tiles.hpp): segments of point runs, their tiles, and the fold table of ba_tile_reduce_kernel
+    int fuse_max_blocks = 4096;        // camera + pair workgroups up to which they share one launch
     bool use_tiles = false; int n_tseg = 0; long long n_ttiles = 0;
     std::vector<TileSeg> tsegs; std::vector<int> tcams;
     TileSeg* d_tsegs = nullptr; int* d_tcams = nullptr; double *d_tpart = nullptr, *d_tpart_seg = nullptr;
@@ -317,11 +317,32 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     // camera items and pair chunks in one launch, then their folds in one launch (ba_kernels.hpp: ba_camschur_kernel)
     const int n_cam_blocks = round_up(h->nc * h->cam_split * (h->fixK ? 1 : 2), 8);
     const int n_schur_blocks = h->nblk > 0 ? round_up(ceil_div(h->nchunk, 4), 8) : 0;
-    if (tv) { (void)hipEventRecord(tv[1], st); (void)hipEventRecord(tv[3], st); }
-    hipLaunchKernelGGL(ba_camschur_kernel, dim3(n_cam_blocks + n_schur_blocks), dim3(256), 0, st, P, n_cam_blocks, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
-    if (tv) { (void)hipEventRecord(tv[2], st); (void)hipEventRecord(tv[4], st); }
-    hipLaunchKernelGGL(ba_fold_kernel, dim3(h->nc + 1 + (h->nblk > 0 ? ceil_div(h->nblk * 36, 256) : 0)), dim3(256), 0, st, P, h->n_pt_blocks,
-                       h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
+    // Up to a few thousand workgroups one launch is ahead (C3: 0.190 -> 0.169 ms per iteration, C4: 0.314 -> 0.306: the fork /
+    // join events cost 5-7 us of stream gap each); beyond that the two kernels on two queues run 15 % faster than the shared
+    // launch (C5: 0.44 || 0.48 ms against 0.56), so large problems keep the auxiliary stream.
+    bool folded = false;
+    if (n_schur_blocks > 0 && n_cam_blocks + n_schur_blocks > h->fuse_max_blocks) {
+        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
+        SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        if (tv) (void)hipEventRecord(tv[3], h->aux);
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(n_schur_blocks), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        if (tv) (void)hipEventRecord(tv[4], h->aux);
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, h->aux, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 0);
+        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_join, h->aux));
+        if (tv) (void)hipEventRecord(tv[1], st);
+        hipLaunchKernelGGL(ba_camera_kernel, dim3(n_cam_blocks), dim3(256), 0, st, P);
+        if (tv) (void)hipEventRecord(tv[2], st);
+        hipLaunchKernelGGL(ba_fold_kernel, dim3(h->nc + 1), dim3(256), 0, st, P, h->n_pt_blocks, h->d_blk_cam, h->d_blk_chunk, 0, h->d_part_schur);      // each stream folds its own kernel's partials
+        SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
+        folded = true;
+    } else {
+        if (tv) { (void)hipEventRecord(tv[1], st); (void)hipEventRecord(tv[3], st); }
+        hipLaunchKernelGGL(ba_camschur_kernel, dim3(n_cam_blocks + n_schur_blocks), dim3(256), 0, st, P, n_cam_blocks, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
+        if (tv) { (void)hipEventRecord(tv[2], st); (void)hipEventRecord(tv[4], st); }
+    }
+    if (!folded)
+        hipLaunchKernelGGL(ba_fold_kernel, dim3(h->nc + 1 + (h->nblk > 0 ? ceil_div(h->nblk * 36, 256) : 0)), dim3(256), 0, st, P, h->n_pt_blocks,
+                           h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur);
     if (h->n_diag_blk > 0)
         hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
     SFM_HIP_TRY(ctx, hipGetLastError());
@@ -958,7 +979,6 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
             seq = ++h->pub_seq;
             hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
         }
-        SFM_HIP_TRY(ctx, hipEventRecord(h->ev_scal, st));
         // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
         // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
         bool speculated = false;
@@ -966,12 +986,12 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
         read_pending_timing(h);                     // the PREVIOUS iteration's events, while the GPU works on this one
         if (timing) { h->pending_build = par; h->pending_iter = h->iter_parity; }
-        {   // spin on the sequence number; fall back to the event if the stream stops without publishing (a failed launch)
+        {   // spin on the sequence number; if the stream drains without publishing (a failed launch) the query ends the wait.
+            // No event behind the publishing kernel: a hipEventRecord there held the next kernel back by ~10 us.
             volatile unsigned long long* flag = (volatile unsigned long long*)(h->h_scal + 15);
             unsigned spins = 0;
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-                if ((++spins & 0x3fff) == 0 && hipEventQuery(h->ev_scal) != hipErrorNotReady) {
-                    SFM_HIP_TRY(ctx, hipEventSynchronize(h->ev_scal));
+                if ((++spins & 0xffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
                     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->last_error = "bundle adjustment: the step scalars were not published"; return SFMHIP_E_HIP; }
                     break;
                 }
@@ -1060,7 +1080,6 @@ void sfmhip_ba_destroy(sfmhip_ba* h)
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     for (auto& pr : h->evb) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     for (auto& pr : h->evi) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
-    if (h->ev_scal) (void)hipEventDestroy(h->ev_scal);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -1254,7 +1273,6 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evb) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evi) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
-    if (hipEventCreateWithFlags(&h->ev_scal, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "auxiliary stream"; return SFMHIP_E_HIP; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "upload failed"; return SFMHIP_E_HIP; }

@@ -800,6 +800,17 @@ __global__ __launch_bounds__(256, 3) void ba_camschur_kernel(BADev P, int n_cam_
     if (upto > before) ba_camera_role(P, red, before * 8 + (blockIdx.x & 7), n_cam_blocks);
     else ba_schur_role(P, chunk_desc, n_chunk, items, part, (g - before) * 8 + (blockIdx.x & 7), gridDim.x - n_cam_blocks);
 }
+// the two roles as launches of their own: large problems run them on two streams (see enqueue_build)
+__global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
+{
+    __shared__ double red[4][CAMACC];
+    ba_camera_role(P, red, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
+                                                       const int4* __restrict__ items, double* __restrict__ part)
+{
+    ba_schur_role(P, chunk_desc, n_chunk, items, part, blockIdx.x, gridDim.x);
+}
 __global__ __launch_bounds__(256) void ba_fold_kernel(BADev P, int n_pt_blocks, const int* __restrict__ blk_cam, const int* __restrict__ blk_chunk,
                                                       int n_blk, const double* __restrict__ part)
 {
