@@ -40,7 +40,8 @@ STORE_CEILING_GBS = 5760.0
 STORE_CEILING_SOURCE = "experiments/wbw4.hip: 400 MB write-only streams, best of the shapes tried (16-byte stores, 16k workgroups: 5.76 TB/s; the guide's 6.0-6.2 TB/s figure was not reproduced, profiles/README.md)"
 SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissection (the longest solver launch)
 RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (2.977e8, "profiles/r01_traffic_pmc.md"),
-                    "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md")}
+                    "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md"),
+                    "ba_camschur_kernel": (9.734e7, "profiles/r02_traffic_pmc.md")}      # FETCH_SIZE + WRITE_SIZE raw (gathers: uncalibrated)
 
 
 def spawn_ranks(n, argv):
@@ -253,19 +254,32 @@ def main():
         # `roofline` is the one with the largest launch time -- the kernel that dominates the region `value` is measured on
         L = np.bincount(sc["obs_pt"], minlength=n_pt).astype(np.int64)
         n_pairs_items = int((L * (L - 1) // 2).sum())
-        kern = {
-            "ba_schur_kernel": dict(ms=phase[5], bytes=n_pairs_items * (8 + 24 + 24 + 48 + 32) + 2 * 36 * 8 * 6 * n_img,
-                                    what="per observation pair: 8 B pair record + 24 B point + 24 B scale + 48 B V^-1 + 2x16 B pixels"),
-            "ba_camera_kernel": dict(ms=phase[4], bytes=n_obs * (4 + 16 + 24 + 24 + 48 + 24 + 96),
-                                     what="per observation: 20 B record + 24 B point + 24 B scale + 48 B V^-1 + 24 B b + 96 B W_K"),
-            SOLVER_KERNEL: dict(ms=phase[6], bytes=2 * 8 * 1024 * phase[7],
-                                what="non-zero 32x32 blocks of S read and of L written"),
-        }
+        # algorithmic bytes of a kernel = what it must move once (compulsory traffic): its records, every point block it reads,
+        # its partial sums; `gather_bytes` = what its threads request (a point's blocks once per observation / pair), mostly
+        # served by the XCD L2s because neighbouring cameras share their points -- reported beside it, not priced against HBM
+        pt_blocks = n_pt * (24 + 24 + 48)                       # point, column scales, V^-1
+        pair_alg = n_pairs_items * 16 + pt_blocks + n_obs * 16 + 36 * 8 * (n_pairs_items // 512 + 6 * n_img)
+        cam_alg = n_obs * 20 + pt_blocks + n_pt * (24 + 96) + 2 * 80 * 8 * n_img
+        pair_gather = n_pairs_items * (16 + 24 + 24 + 48 + 32)
+        cam_gather = 2 * n_obs * (4 + 16 + 24 + 24 + 48) + n_obs * (24 + 96)
+        pair_what = "pair records 16 B + every point's 96 B of blocks once + pixels 16 B per observation + 288 B per partial"
+        cam_what = "observation records 20 B + every point's 96 B of blocks + b_p / W_K 120 B once + partials"
+        kern = {SOLVER_KERNEL: dict(ms=phase[6], bytes=2 * 8 * 1024 * phase[7], gather=None, what="non-zero 32x32 blocks of S read and of L written")}
+        if phase[5] > 0:            # large problems: the pair kernel and the camera kernel as two launches on two streams
+            kern["ba_schur_kernel"] = dict(ms=phase[5], bytes=pair_alg, gather=pair_gather, what=pair_what)
+            kern["ba_camera_kernel"] = dict(ms=phase[4], bytes=cam_alg, gather=cam_gather, what=cam_what)
+        else:                       # one launch runs both kinds of workgroup; the point blocks are shared between them
+            kern["ba_camschur_kernel"] = dict(ms=phase[4], bytes=pair_alg + cam_alg - pt_blocks, gather=pair_gather + cam_gather,
+                                              what=pair_what + "; " + cam_what + " (point blocks counted once)")
         dom = max(kern, key=lambda k: kern[k]["ms"])
         kd = kern[dom]
         roof = {"kernel": dom, "bound": "hbm", "achieved": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kd["bytes"] / max(kd["ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
+                "traffic": RECORDED_TRAFFIC[dom][0] if (dom in RECORDED_TRAFFIC and world == 1 and args.config == "C4") else None,
+                "traffic_source": (RECORDED_TRAFFIC[dom][1] + " (recorded by separate --pmc passes, not measured in this run)")
+                                  if (dom in RECORDED_TRAFFIC and world == 1 and args.config == "C4") else None,
+                "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
+                "gather_bytes_requested": kd["gather"],
                 "note": f"largest kernel of one LM iteration (the region `value` is measured on); the iteration is latency-bound at this size "
                         f"({phase[3]:.3f} ms of device time for {b_it / 1e6:.0f} MB), see roofline_lm_iteration and DESIGN.md 7"}
         roof_knn = None

@@ -249,7 +249,8 @@ int  sfmhip_ba_reduced_system(sfmhip_ba*, double radius, double* S, double* rhs,
 /* average device time (ms) per LM iteration of the last sfmhip_ba_iterate call, measured with HIP events on the
  * context's stream WHILE sfmhip_set_kernel_timing(ctx, 1) is in effect (all zero otherwise: the thirteen event records
  * cost ~27 us per iteration, so they are off by default): [0]=linearise+Schur build, [1]=reduced solve, [2]=back-substitution+cost, [3]=total,
- * single kernels: [4]=ba_camera_kernel, [5]=ba_schur_kernel, [6]=chol_nd_forward_kernel (0 if unused);
+ * single kernels: [4]=ba_camera_kernel, [5]=ba_schur_kernel -- or, where the two share one launch, [4]=ba_camschur_kernel and [5]=0
+ * ([4]=ba_tile_kernel with linearizer = 2) --, [6]=chol_node_forward_kernel of the leaf level (0 if unused);
  * [7] = number of non-zero 32x32 blocks of the Cholesky factor (not a time) */
 int  sfmhip_ba_phase_ms(sfmhip_ba*, double out_ms[8]);
 

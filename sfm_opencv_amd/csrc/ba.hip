@@ -210,6 +210,7 @@ struct sfmhip_ba {
     int n_diag_blk = 0;            // camera pairs (a, a): a point seen twice by one camera
     bool solver_damps = false; double damp_radius = 0.0;    // the next enqueue_solve applies the LM damping inside its kernels
     bool build_timed = false;      // the pending build recorded its events (timing can be switched between launches)
+    bool build_fused[2] = { false, false };      // per build parity: camera items and pair chunks shared one launch (one kernel time, reported in slot 4)
     bool publish_in_back = false, published = false;   // ba_loop asks enqueue_back to publish the step scalars from its reduction kernel
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
@@ -324,7 +325,7 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     if (n_schur_blocks > 0 && n_cam_blocks + n_schur_blocks > h->fuse_max_blocks) {
         SFM_HIP_TRY(ctx, hipEventRecord(h->ev_fork, st));
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        if (tv) (void)hipEventRecord(tv[3], h->aux);
+        if (tv) { (void)hipEventRecord(tv[3], h->aux); h->build_fused[h->build_parity] = false; }
         hipLaunchKernelGGL(ba_schur_kernel, dim3(n_schur_blocks), dim3(256), 0, h->aux, P, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
         if (tv) (void)hipEventRecord(tv[4], h->aux);
         hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, h->aux, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 0);
@@ -336,7 +337,7 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
         SFM_HIP_TRY(ctx, hipStreamWaitEvent(st, h->ev_join, 0));
         folded = true;
     } else {
-        if (tv) { (void)hipEventRecord(tv[1], st); (void)hipEventRecord(tv[3], st); }
+        if (tv) { (void)hipEventRecord(tv[1], st); (void)hipEventRecord(tv[3], st); h->build_fused[h->build_parity] = true; }
         hipLaunchKernelGGL(ba_camschur_kernel, dim3(n_cam_blocks + n_schur_blocks), dim3(256), 0, st, P, n_cam_blocks, h->d_chunk_desc, h->nchunk, h->d_items, h->d_part_schur);
         if (tv) { (void)hipEventRecord(tv[2], st); (void)hipEventRecord(tv[4], st); }
     }
@@ -928,6 +929,7 @@ static void read_pending_timing(sfmhip_ba* h)
     float a = 0, b = 0, c = 0, k1 = 0, k2 = 0, k3 = 0;
     (void)hipEventElapsedTime(&a, tb[0], ti[0]); (void)hipEventElapsedTime(&b, ti[0], ti[1]); (void)hipEventElapsedTime(&c, ti[1], ti[2]);
     (void)hipEventElapsedTime(&k1, tb[1], tb[2]); (void)hipEventElapsedTime(&k2, tb[3], tb[4]);
+    if (h->build_fused[h->pending_build] || h->use_tiles) k2 = 0.0f;
     if (h->use_sparse && h->nseg > 1) (void)hipEventElapsedTime(&k3, ti[3], ti[4]);
     h->phase_acc[0] += a; h->phase_acc[1] += b; h->phase_acc[2] += c; h->phase_acc[3] += a + b + c;
     h->phase_acc[4] += k1; h->phase_acc[5] += k2; h->phase_acc[6] += k3; h->phase_cnt++;
