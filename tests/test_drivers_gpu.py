@@ -48,7 +48,8 @@ def _scene(n_img=5, n_pts=500, n_desc=560, seed=3):
 
 def _oracle_pipeline(K, Rs, Ts, descs, kps, cols):
     n_img, n_desc = len(descs), descs[0].shape[0]
-    ms = [orc.match_features_l2(descs[i], descs[i + 1]) for i in range(n_img - 1)]
+    match = orc.match_features_hamming2 if descs[0].dtype == np.uint8 else orc.match_features_l2
+    ms = [match(descs[i], descs[i + 1]) for i in range(n_img - 1)]
     Ps = [orc.projection_matrix(K, R, T) for R, T in zip(Rs, Ts)]
     inds = [np.full(n_desc, -1, np.int32) for _ in range(n_img)]
     m0 = ms[0]
@@ -108,6 +109,37 @@ def test_nview_driver_with_given_poses_against_the_oracle_pipeline(drivers, tmp_
     got = np.stack([ply["nx"], ply["ny"], ply["nz"]], 1); ref = np.stack([v["nx"], v["ny"], v["nz"]], 1)
     assert np.abs(got - ref).max() <= 1e-6
     assert (tmp_path / "structure_ba.ply").read_bytes()[:300] == formats.ply_bytes(v)[:300]          # header + first vertices
+
+
+def test_nview_driver_binary_descriptors_hamming2(drivers, tmp_path):
+    """The reference's LIVE configuration: AKAZE's 61-byte MLDB rows matched with NORM_HAMMING2 (NView:797, 876).  The extractor
+    itself is not rebuilt, so the rows are synthetic (a random 486-bit code per scene point, 3 % of the bits flipped per view):
+    the driver must route CV_8U descriptors to the Hamming2 kernels and reproduce the oracle pipeline."""
+    K, Rs, Ts, descs, kps, cols, X = _scene()
+    rng = np.random.default_rng(11)
+    n_pts, n_desc = X.shape[0], descs[0].shape[0]
+    code = rng.integers(0, 256, (n_pts, 61), dtype=np.uint8)
+    # _scene() permuted every image's rows; recover which row shows which scene point from the noise-free part of the key points
+    bdescs = []
+    for i in range(len(descs)):
+        p = X @ Rs[i].T + Ts[i]
+        uv = np.stack([K[0, 0] * p[:, 0] / p[:, 2] + K[0, 2], K[1, 1] * p[:, 1] / p[:, 2] + K[1, 2]], 1)
+        d2 = ((kps[i][:, None, :].astype(np.float64) - uv[None, :, :]) ** 2).sum(-1)
+        owner = d2.argmin(1); is_pt = d2.min(1) < 4.0
+        b = rng.integers(0, 256, (n_desc, 61), dtype=np.uint8)
+        flips = np.packbits(rng.random((n_desc, 61, 8)) < 0.03, axis=2).reshape(n_desc, 61)
+        b[is_pt] = code[owner[is_pt]] ^ flips[is_pt]
+        bdescs.append(np.ascontiguousarray(b))
+    feat = tmp_path / "features.bin"
+    features_io.write_features(feat, K, kps, bdescs, cols, poses=list(zip(Rs, Ts)))
+    out = subprocess.run([drivers[0], str(feat), str(tmp_path), "--poses-from-file"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    y0 = formats.read_structure_yml(tmp_path / "structure.yml"); y1 = formats.read_structure_yml(tmp_path / "structure_ba.yml")
+    pts, colors, ptso, so = _oracle_pipeline(K, Rs, Ts, bdescs, kps, cols)
+    assert len(pts) > 300                                   # most scene points were matched through the binary rows
+    assert y0["points"].shape == pts.shape and np.array_equal(y0["colors"], colors)
+    assert (np.linalg.norm(y0["points"] - pts, axis=1) <= 1e-5 * np.linalg.norm(pts, axis=1)).all()
+    assert np.abs(y1["points"] - ptso).max() <= 1e-5 * np.abs(ptso).max()
 
 
 def test_nview_driver_stand_alone_quality(drivers, tmp_path):
