@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "sfm_ops.hpp"
+#include "sfm_jpeg.hpp"
 
 namespace sfm {
 
@@ -34,12 +35,21 @@ struct Image {
     const uint8_t* at(int y, int x) const { return &data[((size_t)y * cols + x) * channels]; }
 };
 
-// binary PPM (P6, RGB -> stored BGR) / PGM (P5); maxval 255
+// baseline JPEG (sfm_jpeg.hpp: the pixels libjpeg / cv::imread produce) or binary PPM (P6, RGB -> stored BGR) / PGM (P5), maxval 255
 inline Image imread(const std::string& path)
 {
     Image img;
     std::ifstream f(path, std::ios::binary);
     if (!f) return img;
+    if (f.get() == 0xFF && f.get() == 0xD8) {
+        f.seekg(0, std::ios::end);
+        std::vector<uint8_t> bytes((size_t)f.tellg());
+        f.seekg(0);
+        f.read((char*)bytes.data(), (std::streamsize)bytes.size());
+        if (!f || !jpeg::decode_jpeg(bytes.data(), bytes.size(), img.rows, img.cols, img.channels, img.data)) return Image();
+        return img;
+    }
+    f.clear(); f.seekg(0);
     std::string magic;
     f >> magic;
     if (magic != "P6" && magic != "P5") return img;

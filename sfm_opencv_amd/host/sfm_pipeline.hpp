@@ -102,7 +102,10 @@ inline int get_files_format(const std::string& path, const std::string& format, 
     std::vector<std::string> names;
     while (dirent* e = readdir(d)) {
         const std::string n = e->d_name;
-        if (n.size() > format.size() && n.compare(n.size() - format.size(), format.size(), format) == 0) names.push_back(n);
+        if (n.size() <= format.size()) continue;
+        std::string tail = n.substr(n.size() - format.size());
+        for (auto& ch : tail) ch = (char)tolower((unsigned char)ch);       // the reference matches ".jpg" only (NView:1344); its own crazyhorse files are ".JPG"
+        if (tail == format) names.push_back(n);
     }
     closedir(d);
     std::sort(names.begin(), names.end());
@@ -358,7 +361,7 @@ inline int run_twoview(Features& f, const PipelineOptions& opt)
 inline int driver_main(int argc, char** argv, bool nview)
 {
     if (argc < 2 || std::string(argv[1]).empty()) {
-        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.ppm) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
+        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.jpg | .ppm | .pgm, K.txt beside them) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
         return 0;
     }
     PipelineOptions opt;
@@ -377,9 +380,11 @@ inline int driver_main(int argc, char** argv, bool nview)
     }
     Features f;
     if (is_directory(argv[1])) {
-        // the reference's own entry: a directory of images (binary .ppm / .pgm here: no JPEG decoder is built)
+        // the reference's own entry: a directory of images (.jpg / .jpeg through sfm_jpeg.hpp, else binary .ppm / .pgm)
         std::vector<std::string> img_names;
-        int n_files = get_files_format(argv[1], ".ppm", img_names);
+        int n_files = get_files_format(argv[1], ".jpg", img_names);
+        if (n_files == 0) n_files = get_files_format(argv[1], ".jpeg", img_names);
+        if (n_files == 0) n_files = get_files_format(argv[1], ".ppm", img_names);
         if (n_files == 0) n_files = get_files_format(argv[1], ".pgm", img_names);
         printf("Total %d image files.\n", n_files);
         f.K = load_K(argv[1]);
