@@ -394,8 +394,16 @@ inline void sift_detect_and_compute(const Image& img, std::vector<KeyPoint>& key
 
 // extract_features (NView:785-848; SIFT as in TwoViewReconstruct.cpp:112): images that cannot be read or give <= 10 key
 // points are skipped; colours are the BGR pixel under each key point (bounds test as written there, clamped to the image)
+}  // namespace sfm
+#include "sfm_akaze.hpp"
+namespace sfm {
+
+// which extractor extract_features runs: the reference's live one is AKAZE (NView:797), its commented twin SIFT (NView:798, TwoView:112)
+enum Extractor { EXTRACT_SIFT = 0, EXTRACT_AKAZE = 1 };
+
 inline void extract_features(std::vector<std::string>& image_names, std::vector<std::vector<KeyPoint>>& key_points_for_all,
-                             std::vector<Mat>& descriptor_for_all, std::vector<std::vector<Vec3b>>& colors_for_all, int max_features = 0)
+                             std::vector<Mat>& descriptor_for_all, std::vector<std::vector<Vec3b>>& colors_for_all, int max_features = 0,
+                             Extractor extractor = EXTRACT_SIFT)
 {
     key_points_for_all.clear(); descriptor_for_all.clear(); colors_for_all.clear();
     sift::Params P; P.nfeatures = max_features;
@@ -404,7 +412,8 @@ inline void extract_features(std::vector<std::string>& image_names, std::vector<
         if (img.empty()) continue;
         printf("Extracting features for image %s...\n", name.c_str());
         std::vector<KeyPoint> key_points; Mat descriptor;
-        sift_detect_and_compute(img, key_points, descriptor, P);
+        if (extractor == EXTRACT_AKAZE) akaze_detect_and_compute(img, key_points, descriptor, max_features);
+        else sift_detect_and_compute(img, key_points, descriptor, P);
         if (key_points.size() <= 10) continue;
         printf("%zd 2D feature point detected.\n", key_points.size());
         std::vector<Vec3b> colors(key_points.size());

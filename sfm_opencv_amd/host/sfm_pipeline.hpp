@@ -226,6 +226,7 @@ struct PipelineOptions {
     int max_features = 0;                  // directory input: keep the strongest N key points per image (0: all, like the reference)
     std::string save_features;             // directory input: also write the extracted features to this file
     bool features_only = false;            // ... and stop there
+    bool akaze = false;                    // directory input: AKAZE + M-LDB rows (the reference's live extractor, NView:797) instead of SIFT (its commented twin)
     double refine_px = 0.0;                // > 0: after BA, refine_structure(max_px) + a second BA (extension, not reference behaviour)
 };
 
@@ -361,7 +362,7 @@ inline int run_twoview(Features& f, const PipelineOptions& opt)
 inline int driver_main(int argc, char** argv, bool nview)
 {
     if (argc < 2 || std::string(argv[1]).empty()) {
-        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.jpg | .ppm | .pgm, K.txt beside them) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
+        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.jpg | .ppm | .pgm, K.txt beside them) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--akaze | --sift] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
         return 0;
     }
     PipelineOptions opt;
@@ -372,6 +373,8 @@ inline int driver_main(int argc, char** argv, bool nview)
         else if (a == "--write-back-poses") opt.write_back_poses = true;
         else if (a == "--quiet") opt.print_offsets = false;
         else if (a == "--features-only") opt.features_only = true;
+        else if (a == "--akaze") opt.akaze = true;
+        else if (a == "--sift") opt.akaze = false;
         else if (a.rfind("--max-features=", 0) == 0) opt.max_features = std::atoi(a.c_str() + 15);
         else if (a == "--refine") opt.refine_px = 4.0;
         else if (a.rfind("--refine=", 0) == 0) opt.refine_px = std::atof(a.c_str() + 9);
@@ -388,7 +391,7 @@ inline int driver_main(int argc, char** argv, bool nview)
         if (n_files == 0) n_files = get_files_format(argv[1], ".pgm", img_names);
         printf("Total %d image files.\n", n_files);
         f.K = load_K(argv[1]);
-        extract_features(img_names, f.key_points_for_all, f.descriptor_for_all, f.colors_for_all, opt.max_features);
+        extract_features(img_names, f.key_points_for_all, f.descriptor_for_all, f.colors_for_all, opt.max_features, opt.akaze ? EXTRACT_AKAZE : EXTRACT_SIFT);
         f.file_rotations.assign(f.key_points_for_all.size(), Mat()); f.file_motions.assign(f.key_points_for_all.size(), Mat());
         if (!opt.save_features.empty() && !write_features(opt.save_features, f)) printf("[Warning]: cannot write %s\n", opt.save_features.c_str());
     } else {

@@ -6,6 +6,7 @@
 //                                            out: ok(int) rvec(3) T(3) R(9) n_inliers
 //   geom_test rodrigues <in.bin> <out.bin>   in: n, rvec (n x 3 double)   out: R (n x 9), back (n x 3)
 //   geom_test features <image.ppm> <out.bin> [max]  out: n, key points (n x 28 B), descriptors (n x 128 float), colours (n x 3)
+//   geom_test features_akaze <image> <out.bin> [max]  same with AKAZE: descriptors n x 61 bytes
 #include "../../sfm_opencv_amd/host/sfm_features.hpp"
 #include "../../sfm_opencv_amd/host/sfm_geometry.hpp"
 using namespace sfm;
@@ -14,10 +15,10 @@ int main(int argc, char** argv)
 {
     if (argc < 4) return 2;
     const std::string mode = argv[1];
-    if (mode == "features") {
+    if (mode == "features" || mode == "features_akaze") {
         std::vector<std::string> names = { argv[2] };
         std::vector<std::vector<KeyPoint>> kps; std::vector<Mat> descs; std::vector<std::vector<Vec3b>> cols;
-        extract_features(names, kps, descs, cols, argc > 4 ? std::atoi(argv[4]) : 0);
+        extract_features(names, kps, descs, cols, argc > 4 ? std::atoi(argv[4]) : 0, mode == "features" ? EXTRACT_SIFT : EXTRACT_AKAZE);
         std::ofstream o(argv[3], std::ios::binary);
         const int n = kps.empty() ? 0 : (int)kps[0].size();
         o.write((const char*)&n, 4);

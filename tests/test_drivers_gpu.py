@@ -239,3 +239,23 @@ def test_twoview_driver_on_crazyhorse(drivers, tmp_path):
         p = X @ R.T + T
         uv = np.stack([K[0, 0] * p[:, 0] / p[:, 2] + K[0, 2], K[1, 1] * p[:, 1] / p[:, 2] + K[1, 2]], 1)
         assert ((uv[:, 0] > -50) & (uv[:, 0] < 1074) & (uv[:, 1] > -50) & (uv[:, 1] < 818)).mean() > 0.98
+
+
+def test_nview_driver_on_crazyhorse_with_akaze_rows(drivers, tmp_path):
+    """BASELINE.json configs[1] in the reference's LIVE configuration: AKAZE key points + 61-byte M-LDB rows (this repo's
+    sfm_akaze.hpp on the reference's seven JPEGs, tests/golden/make_crazyhorse_features.py) matched under NORM_HAMMING2 on the GPU,
+    then the same stages as above.  Quality test, parity unpinned."""
+    out = subprocess.run([drivers[0], os.path.join(GOLD, "crazyhorse_features_akaze.bin"), str(tmp_path), "--quiet"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    log = out.stdout
+    assert "Total 7 image files." in log and "Save structure done." in log
+    v = re.search(r"#views: (\d+)\n #residuals: (\d+)\n Initial RMSE\(pixel\): ([0-9.eE+-]+)\n Final   RMSE\(pixel\): ([0-9.eE+-]+)", log)
+    assert v, log[-2000:]
+    views, nres, r0, r1 = int(v.group(1)), int(v.group(2)), float(v.group(3)), float(v.group(4))
+    assert views == 7 and nres > 2000 and r1 < 0.8 and r1 < r0
+    y0 = formats.read_structure_yml(tmp_path / "structure.yml"); y1 = formats.read_structure_yml(tmp_path / "structure_ba.yml")
+    assert len(y0["rotations"]) == 7 and y0["points"].shape[0] > 300
+    yaw = [np.degrees(np.arctan2(R[0, 2], R[2, 2])) for R in y0["rotations"]]
+    assert all(b > a for a, b in zip(yaw, yaw[1:])) and 5 < yaw[-1] < 40          # the same sweep the SIFT run recovers
+    z = y1["points"][:, 2]
+    assert np.median(z) > 2 and (z > 0).mean() > 0.9

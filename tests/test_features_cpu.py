@@ -110,3 +110,53 @@ def test_feature_budget_and_poor_images(exe, tmp_path):
     _write_ppm(tmp_path / "flat.ppm", np.full((120, 160), 128.0))
     k0, _, _ = _features(exe, tmp_path / "flat.ppm", tmp_path / "f.bin")
     assert len(k0) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AKAZE + M-LDB (sfm_akaze.hpp): the reference's live extractor (NViewReconstuct.cpp:797), parity unpinned like the SIFT
+# ---------------------------------------------------------------------------------------------------------------------
+def _features_akaze(exe, path, out, nmax=0):
+    subprocess.check_call([exe, "features_akaze", str(path), str(out)] + ([str(nmax)] if nmax else []), stdout=subprocess.DEVNULL)
+    raw = open(out, "rb").read()
+    n = struct.unpack_from("<i", raw, 0)[0]
+    kp = np.frombuffer(raw, api.KEYPOINT, n, 4)
+    d = np.frombuffer(raw, np.uint8, n * 61, 4 + 28 * n).reshape(n, 61)
+    return kp, d
+
+
+def test_akaze_rows_and_hamming2_matching_under_a_similarity(exe, tmp_path):
+    img = _texture(480, 640, 6)
+    th = np.radians(-23.0); sc = 1.4          # two sublevels of the scale space: AKAZE's scales are quantised (integer derivative steps, no interpolation)
+    A = sc * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]); t = np.array([-30.0, 140.0])
+    _write_ppm(tmp_path / "a.ppm", img); _write_ppm(tmp_path / "b.ppm", _warp(img, A, t))
+    k1, d1 = _features_akaze(exe, tmp_path / "a.ppm", tmp_path / "a.bin")
+    k2, d2 = _features_akaze(exe, tmp_path / "b.ppm", tmp_path / "b.bin")
+    assert len(k1) > 150 and len(k2) > 100
+    for d in (d1, d2):
+        assert d.shape[1] == 61 and (d[:, 60] >> 6 == 0).all()          # 486 bits: the last two of byte 60 stay clear
+        ones = np.unpackbits(d, axis=1).sum(1)
+        assert 150 < np.median(ones) < 340                              # comparisons of cell means: neither empty nor saturated rows
+    assert (k1["size"] > 2).all() and (k1["angle"] >= 0).all() and (k1["angle"] < 360).all() and (k1["response"] > 0.001).all()
+    # the reference's live matcher: kNN-2 under NORM_HAMMING2 + ratio 0.6 + the absolute gate (oracle restatement)
+    m = orc.match_features_hamming2(d1, d2)
+    assert len(m) > 40
+    p1 = np.stack([k1["x"][m["queryIdx"]], k1["y"][m["queryIdx"]]], 1); p2 = np.stack([k2["x"][m["trainIdx"]], k2["y"][m["trainIdx"]]], 1)
+    err = np.linalg.norm(p1 @ A.T + t - p2, axis=1)
+    assert (err < 2.5).mean() > 0.9 and np.median(err) < 1.0
+    ok = err < 2.5
+    ratio = k2["size"][m["trainIdx"]][ok] / k1["size"][m["queryIdx"]][ok]
+    assert abs(np.median(ratio) - sc) < 0.25
+    dang = (k2["angle"][m["trainIdx"]][ok] - k1["angle"][m["queryIdx"]][ok] + 540) % 360 - 180
+    assert abs(abs(np.median(dang)) - 23.0) < 5.0
+
+
+def test_akaze_budget_and_flat_image(exe, tmp_path):
+    img = _texture(300, 400, 12)
+    _write_ppm(tmp_path / "a.ppm", img)
+    k_all, _ = _features_akaze(exe, tmp_path / "a.ppm", tmp_path / "a.bin")
+    k_top, d_top = _features_akaze(exe, tmp_path / "a.ppm", tmp_path / "t.bin", nmax=40)
+    assert len(k_all) > 60 and len(k_top) == 40 and d_top.shape == (40, 61)
+    assert k_top["response"].min() >= np.sort(k_all["response"])[-41]
+    _write_ppm(tmp_path / "flat.ppm", np.full((200, 240), 128.0))
+    k0, _ = _features_akaze(exe, tmp_path / "flat.ppm", tmp_path / "f.bin")
+    assert len(k0) == 0
