@@ -1032,6 +1032,9 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
                 h->radius = h->radius / h->nu; h->nu *= 2.0;
             }
         }
+#ifdef SFMHIP_EXPERIMENTS
+        if (o.verbose) fprintf(stderr, "[sfmhip_ba dbg] err %d mcc %.6e cand %.12e dn %.3e\n", err, mcc, cand_raw, dn);
+#endif
         if (o.verbose)
             printf("[sfmhip_ba] it %d cost %.12e gmax %.3e radius %.3e %s\n", h->iter, h->x_cost, gmax, h->radius, accepted ? "ok" : "rejected");
     }

@@ -678,6 +678,10 @@ __device__ __forceinline__ void ba_finalize_role(const BADev& P, int n_pt_blocks
         P.scal[SCAL_COST] = sh[0];
         P.scal[SCAL_GMAX_SLOTS + P.rank] = sh[15];
     }
+    // padding slots of the message tail: nothing else writes them, and the solver leaves its forward-substitution result in rhs --
+    // after a factorisation that broke down (NaN) they would poison every later solve
+    for (int i = tid; i < P.npad; i += 256)
+        if (!P.posmask[i]) { P.rhs[i] = 0.0; P.diagU[i] = 0.0; P.graw[i] = 0.0; }
     if (!P.fixK) {
         if (tid < 16) {
             const int i = tid / 4, j = tid % 4;
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256) void ba_damp_kernel(BADev P)
     __shared__ double red[4];
     double g = 0.0;
     for (int i = threadIdx.x; i < P.npad; i += 256) {
-        if (P.posmask[i]) {
+        if (P.posmask[i] && P.diagU[i] > 0.0) {        // diagU == 0: a parameter no residual touches stays put (unit row, like a padding slot)
             const double d = fmin(fmax(P.diagU[i], P.min_diag), P.max_diag) / P.radius;
             P.S[(size_t)i * P.npad + i] += d;
             g = fmax(g, fabs(P.graw[i] / P.scale_c[i]));

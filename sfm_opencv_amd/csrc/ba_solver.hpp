@@ -258,7 +258,9 @@ struct SolverPlan {
     long long* stamps;           // diagnostic (SFMHIP_SOLVER_STAMPS): s_memtime at the phase boundaries of each panel, 8 per panel
     double* linv;                // (L_kk^-1)' of every pivot block, 32x32 each, written by the forward sweep for the backward one
     // LM damping applied by the solver kernels themselves (one launch less per iteration): S_ii += clamp(diagU_i) / radius on
-    // real parameters, unit diagonal on padding slots; damp_diagU == nullptr: the caller has damped S already
+    // real parameters, unit diagonal on padding slots AND on parameters no residual touches (diagU == 0: their row and column of S
+    // and their gradient are zero; Ceres never sees such blocks -- only blocks of added residuals enter the problem, NView:1187-1197 --
+    // so they stay where they are instead of making S + D singular as the radius grows); damp_diagU == nullptr: the caller has damped S already
     const double* damp_diagU; const int* damp_mask; double damp_radius, damp_min, damp_max;
 };
 
@@ -567,7 +569,7 @@ __device__ __forceinline__ void damp_rows(double* __restrict__ A, int ld, const 
     if (!pl.damp_diagU) return;
     for (int i = i0 + (int)threadIdx.x; i < i1; i += STHREADS) {
         double* d = A + (size_t)i * ld + i;
-        if (pl.damp_mask[i]) *d += fmin(fmax(pl.damp_diagU[i], pl.damp_min), pl.damp_max) / pl.damp_radius;
+        if (pl.damp_mask[i] && pl.damp_diagU[i] > 0.0) *d += fmin(fmax(pl.damp_diagU[i], pl.damp_min), pl.damp_max) / pl.damp_radius;      // diagU == 0: no residual touches the parameter (see SolverPlan)
         else *d = 1.0;
     }
 }
@@ -618,7 +620,7 @@ __device__ __forceinline__ void fold_node(FoldEnt* __restrict__ sE, const FoldEn
                     for (int q = 0; q < NSRC; ++q)
                         if (q < E.nsrc) t[u][q] = *(const v2d*)(E.src[q] + (size_t)r * E.src_ld[q] + c);
                     dmp[u] = 0.0; msk[u] = 1;
-                    if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) { dmp[u] = pl.damp_diagU[E.diag0 + r]; msk[u] = pl.damp_mask[E.diag0 + r]; }
+                    if (E.diag0 >= 0 && pl.damp_diagU && (r >> 1) == (tid & 15)) { dmp[u] = pl.damp_diagU[E.diag0 + r]; msk[u] = pl.damp_mask[E.diag0 + r] && dmp[u] > 0.0; }
                 }
             if (d0 == 0 && rhs_mine) {
                 const FoldEnt& E = sE[rdi];

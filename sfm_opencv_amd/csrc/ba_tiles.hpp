@@ -349,6 +349,8 @@ __global__ __launch_bounds__(256) void ba_tile_reduce_kernel(BADev P, const int*
             P.scal[SCAL_COST] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
             P.scal[SCAL_GMAX_SLOTS + P.rank] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
         }
+        for (int i = tid; i < P.npad; i += 256)          // padding slots of the message tail (see ba_finalize_role)
+            if (!P.posmask[i]) { P.rhs[i] = 0.0; P.diagU[i] = 0.0; P.graw[i] = 0.0; }
         return;
     }
     if ((int)blockIdx.x < n_long) {

@@ -395,3 +395,33 @@ def test_run_tiles_two_point_shards_match_unsharded(ctx):
         assert abs(out[r]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
         K, ext, pts = params[r]
         assert np.abs(ext - extr).max() <= 1e-8 and np.abs(pts - ptsr[ids[r]]).max() <= 1e-8
+
+
+def test_parameters_without_residuals_stay_put(ctx):
+    """A camera no observation refers to (Ceres never sees such a block: only the blocks of added residuals enter the problem,
+    NViewReconstuct.cpp:1187-1197) and points without observations: zero rows of the reduced system.  They must neither move nor make
+    the damped system singular as the radius grows; everything else follows the oracle."""
+    sc = synth.ba_scene(8, 300)
+    keep = sc["obs_pt"] % 10 != 3                                   # every tenth point loses all its observations
+    ext0 = np.vstack([sc["ext0"], sc["ext0"][5] + 0.01])            # a ninth camera that sees nothing
+    a = (sc["K0"], ext0, sc["pts0"], sc["obs_cam"][keep], sc["obs_pt"][keep], sc["obs_uv"][keep])
+    K, ext, pts, s = ctx.ba_solve(*a)
+    Ko, exto, ptso, so, _ = orc.ba_solve(*a)
+    assert s["termination"] == so["termination"] == 0 and s["iterations"] == so["iterations"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+    assert np.array_equal(ext[8], ext0[8]) and np.array_equal(pts[3::10], sc["pts0"][3::10])
+    assert np.abs(ext - exto).max() <= 1e-7 and np.abs(pts - ptso).max() <= 1e-7
+    # a factorisation that breaks down must not poison the following iterations: with single-observation points (camera 7's
+    # observations dropped) S + D loses definiteness once the radius passes ~5e9; the step is invalid, the radius shrinks, LM goes on
+    keep2 = keep & (sc["obs_cam"] != 7)
+    b = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"][keep2], sc["obs_pt"][keep2], sc["obs_uv"][keep2])
+    pb = ctx.ba_create(*b)
+    s2 = pb.iterate(30)
+    assert np.isfinite(s2["final_cost"]) and s2["final_cost"] < 2640.0 and s2["successful_steps"] >= 12
+    Kb, extb, ptsb = pb.params(); pb.close()
+    assert np.isfinite(extb).all() and np.isfinite(ptsb).all() and np.array_equal(extb[7], sc["ext0"][7])
+    # no observations at all / no points: nothing to do, not an error
+    for b in ((sc["K0"], sc["ext0"], sc["pts0"], np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2))),
+              (sc["K0"], sc["ext0"], np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))):
+        _, e3, _, s3 = ctx.ba_solve(*b)
+        assert s3["termination"] == 0 and s3["final_cost"] == 0.0 and np.array_equal(e3, sc["ext0"])
