@@ -407,24 +407,42 @@ inline void extract_features(std::vector<std::string>& image_names, std::vector<
 {
     key_points_for_all.clear(); descriptor_for_all.clear(); colors_for_all.clear();
     sift::Params P; P.nfeatures = max_features;
-    for (const auto& name : image_names) {
-        const Image img = imread(name);
+    // images are independent: extracted in parallel (OpenMP, when the driver is built with it), reported and stored in file order
+    const int n = (int)image_names.size();
+    std::vector<std::vector<KeyPoint>> kps((size_t)n); std::vector<Mat> descs((size_t)n); std::vector<std::vector<Vec3b>> cols((size_t)n);
+    std::vector<int> state((size_t)n, 0);           // 0: unreadable, 1: too few key points, 2: kept
+    std::vector<std::string> warnings((size_t)n);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 0; k < n; ++k) {
+        const Image img = imread(image_names[(size_t)k]);
         if (img.empty()) continue;
-        printf("Extracting features for image %s...\n", name.c_str());
-        std::vector<KeyPoint> key_points; Mat descriptor;
+        std::vector<KeyPoint>& key_points = kps[(size_t)k]; Mat& descriptor = descs[(size_t)k];
         if (extractor == EXTRACT_AKAZE) akaze_detect_and_compute(img, key_points, descriptor, max_features);
         else sift_detect_and_compute(img, key_points, descriptor, P);
+        state[(size_t)k] = 1;
         if (key_points.size() <= 10) continue;
-        printf("%zd 2D feature point detected.\n", key_points.size());
-        std::vector<Vec3b> colors(key_points.size());
+        state[(size_t)k] = 2;
+        std::vector<Vec3b>& colors = cols[(size_t)k];
+        colors.resize(key_points.size());
         for (size_t i = 0; i < key_points.size(); ++i) {
             const int y = (int)key_points[i].pt.y, x = (int)key_points[i].pt.x;
             if (y <= img.rows && x <= img.cols) {
                 const uint8_t* p = img.at(std::min(std::max(y, 0), img.rows - 1), std::min(std::max(x, 0), img.cols - 1));
                 for (int ch = 0; ch < 3; ++ch) colors[i][ch] = img.channels == 3 ? p[ch] : p[0];
-            } else printf("[Warning]: pt2d[%.3f, %.3f] out of image range.\n", key_points[i].pt.x, key_points[i].pt.y);
+            } else {
+                char line[160];
+                snprintf(line, sizeof line, "[Warning]: pt2d[%.3f, %.3f] out of image range.\n", key_points[i].pt.x, key_points[i].pt.y);
+                warnings[(size_t)k] += line;
+            }
         }
-        key_points_for_all.push_back(std::move(key_points)); descriptor_for_all.push_back(std::move(descriptor)); colors_for_all.push_back(std::move(colors));
+    }
+    for (int k = 0; k < n; ++k) {
+        if (state[(size_t)k] == 0) continue;
+        printf("Extracting features for image %s...\n", image_names[(size_t)k].c_str());
+        if (state[(size_t)k] == 1) continue;
+        printf("%zd 2D feature point detected.\n", kps[(size_t)k].size());
+        if (!warnings[(size_t)k].empty()) fputs(warnings[(size_t)k].c_str(), stdout);
+        key_points_for_all.push_back(std::move(kps[(size_t)k])); descriptor_for_all.push_back(std::move(descs[(size_t)k])); colors_for_all.push_back(std::move(cols[(size_t)k]));
     }
 }
 
