@@ -364,8 +364,8 @@ __device__ __forceinline__ float sqrt_exact_int(float x)
 template <int KS>
 __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
                                                          const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
-                                                         int nq, int nt, int nt_pad, int blocks_per_wg,
-                                                         float* __restrict__ dist, size_t ldd, int vec_ok, int exp_mode_arg)
+                                                         int nq, int nq_pad, int nt, int nt_pad, int blocks_per_wg,
+                                                         float* __restrict__ dist, size_t ldd, int vec_ok, int parity_mode, int exp_mode_arg)
 {
 #ifdef SFMHIP_EXPERIMENTS
     const int exp_mode = exp_mode_arg;      // timing experiments (SFMHIP_EXP_DISTMAT; results are wrong with it set)
@@ -385,21 +385,28 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     // adjacent tiles -- which share the 128-B lines straddling their common edge whenever the row stride is not a
     // multiple of 32 floats (the reference's dense 10000-column cv::Mat) -- pass through ONE L2 one after the other and
     // leave it as whole lines.  Pure-writer check (experiments/wbw4.hip): 103 -> 88 us at stride 10000, 82 -> 76 us aligned.
-    const int n_qb = (nq + 127) >> 7, n_tb = (nt_pad / 128 + blocks_per_wg - 1) / blocks_per_wg;
+    // parity_mode (row stride = 64 B mod 128 B, the reference's dense 10000-column cv::Mat: odd rows start half-way into a
+    // 128-B line): a workgroup takes 128 rows of ONE parity out of 256 consecutive ones and the odd ones shift their train
+    // window 16 columns down, so that every 512-B row segment a wave stores starts on a line boundary and no line is
+    // shared between two workgroups (93-103 us -> the aligned layout's 77-80 us at 10k x 10k, profiles/README.md).
+    const int n_qb = parity_mode ? 2 * ((nq + 255) >> 8) : (nq + 127) >> 7;
+    const int n_tb = (nt_pad / 128 + (parity_mode ? 1 : 0) + blocks_per_wg - 1) / blocks_per_wg;
     const int L = blockIdx.x, slot = L >> 3;
     const int qb = (slot / n_tb) * 8 + (L & 7), tb = slot % n_tb;
     if (qb >= n_qb) return;
-    const int q0 = qb * 128 + wave * 32;
-    const int t_begin = tb * blocks_per_wg * 128;
-    int nblocks = (nt_pad - t_begin) / 128; if (nblocks > blocks_per_wg) nblocks = blocks_per_wg;
-    if (nblocks <= 0) return;
+    const int qbase = parity_mode ? (qb >> 1) * 256 + (qb & 1) : qb * 128, qstep = parity_mode ? 2 : 1;      // row i of the tile: qbase + qstep * i
+    const int q0i = wave * 32;
+    const int t_begin = tb * blocks_per_wg * 128 - ((parity_mode && (qb & 1)) ? 16 : 0);
+    int nblocks = (nt_pad - t_begin + 127) / 128; if (nblocks > blocks_per_wg) nblocks = blocks_per_wg;
+    if (nblocks <= 0 || t_begin >= nt) return;
 
+    const int qrow = qbase + qstep * (q0i + l31);
+    const int qrow_ld = qrow < nq_pad ? qrow : nq_pad - 1;
     v4i qfrag[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        qfrag[ks] = *(const v4i*)(Q + (size_t)(q0 + l31) * DP + 32 * ks + 16 * half);
-    const int qrow = q0 + l31;
-    const int qn = qnorm[qrow];
+        qfrag[ks] = *(const v4i*)(Q + (size_t)qrow_ld * DP + 32 * ks + 16 * half);
+    const int qn = qnorm[qrow_ld];
 
     int* lds_norm = (int*)(lds + 2 * 128 * DP);
     v4i stage[PASSES];
@@ -408,9 +415,10 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
-            stage[p] = *(const v4i*)(T + (size_t)(t_begin + blk * 128 + r) * DP + 16 * c);
+            int tr = t_begin + blk * 128 + r; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1);       // shifted windows reach 16 rows past either end
+            stage[p] = *(const v4i*)(T + (size_t)tr * DP + 16 * c);
         }
-        if (tid < 128) stage_norm = tnorm[t_begin + blk * 128 + tid];
+        if (tid < 128) { int tr = t_begin + blk * 128 + tid; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1); stage_norm = tnorm[tr]; }
     };
     auto l_store = [&](int buf) {
 #pragma unroll
@@ -473,8 +481,8 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 4;
                 const float4 o = *(const float4*)(slab + row * 36 + col);
-                const int qr = q0 + row, tg = tg0 + col;
-                if (qr < nq && !((exp_mode & 2) && o.x != -12345.0f)) {
+                const int qr = qbase + qstep * (q0i + row), tg = tg0 + col;
+                if (qr < nq && tg >= 0 && !((exp_mode & 2) && o.x != -12345.0f)) {
                     float* dst = dist + (size_t)qr * ldd + tg;
                     if (vec_ok && tg + 3 < nt) {
                         { v4f ov = { o.x, o.y, o.z, o.w }; if (exp_mode & 8) __builtin_nontemporal_store(ov, (v4f*)dst); else *(v4f*)dst = ov; }      // plain stores: a 400 MB write stream measures 5.5 TB/s plain vs 4.9 nontemporal (experiments/wbw2.hip)
@@ -1283,12 +1291,17 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
         if (const char* em = getenv("SFMHIP_EXP_DISTMAT")) exp_mode = atoi(em);
         if (const char* eb = getenv("SFMHIP_EXP_BPW")) bpw = atoi(eb);
 #endif
-        const int n_qb = ceil_div(query->rows, 128), n_tb = ceil_div(train->rows_pad / 128, bpw);
-        const dim3 grid((unsigned)(8 * ceil_div(n_qb, 8) * n_tb));     // decoded in the kernel (XCD-banded mapping)
         const int vec_ok = (ld % 4 == 0) && ((uintptr_t)d_dist % 16 == 0);
+        // rows alternate between line-aligned and half-a-line-off (ld = 16 mod 32 floats, e.g. the reference's 10000-column matrix)
+        int parity = vec_ok && (ld % 32 == 16) && ((uintptr_t)d_dist % 128 == 0);
+#ifdef SFMHIP_EXPERIMENTS
+        if (getenv("SFMHIP_EXP_NO_PARITY")) parity = 0;
+#endif
+        const int n_qb = parity ? 2 * ceil_div(query->rows, 256) : ceil_div(query->rows, 128), n_tb = ceil_div(train->rows_pad / 128 + (parity ? 1 : 0), bpw);
+        const dim3 grid((unsigned)(8 * ceil_div(n_qb, 8) * n_tb));     // decoded in the kernel (XCD-banded mapping)
         const int ks = query->dim_pad / 32;
 #define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
-                                        train->d_i8, train->d_norm, query->rows, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok, exp_mode)
+                                        train->d_i8, train->d_norm, query->rows, query->rows_pad, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok, parity, exp_mode)
         if (ks == 1) DM_LAUNCH(1); else if (ks == 2) DM_LAUNCH(2); else DM_LAUNCH(4);
 #undef DM_LAUNCH
         SFM_HIP_TRY(ctx, hipGetLastError());

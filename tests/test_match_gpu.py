@@ -142,6 +142,22 @@ def test_distance_matrix(ctx):
         got = out.cpu().numpy()
         assert np.array_equal(got[:, :590].view(np.uint32), ref.view(np.uint32))
         assert (got[:, 590:] == -1.0).all()
+    # row stride = 16 mod 32 floats (the reference's dense 10000-column matrix): rows alternate between line-aligned and half a
+    # line off, and the kernel tiles by row parity with the odd rows' train window shifted by 16 columns.  592 above is such a
+    # stride; here more than one 256-row group, a train count that ends inside a shifted window, and a base address that defeats it
+    descs = synth.sift_descriptor_chain(2, 1100, seed=45)
+    q, t = descs[0][:700], descs[1][:1008]
+    qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
+    ref = orc.l2_distance_matrix(q, t)
+    for nt_use, base_off in ((1008, 0), (1001, 0), (1008, 16)):
+        tsu = ctx.descset_l2(t[:nt_use])
+        buf = torch.full((700 * 1008 + 64,), -1.0, device="cuda", dtype=torch.float32)
+        out = buf[base_off:base_off + 700 * 1008].view(700, 1008)
+        ctx.l2_distance_matrix_dev(qs, tsu, out[:, :nt_use] if nt_use == 1008 else out)
+        ctx.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :nt_use].view(np.uint32), ref[:, :nt_use].view(np.uint32))
+        assert (got[:, nt_use:] == -1.0).all() and (buf[:base_off].cpu().numpy() == -1.0).all() and (buf[base_off + 700 * 1008:].cpu().numpy() == -1.0).all()
     # general float inputs: exact path
     rng = np.random.default_rng(1)
     qf = rng.standard_normal((50, 128)).astype(np.float32); tf = rng.standard_normal((90, 128)).astype(np.float32)
