@@ -19,6 +19,9 @@ struct sfmhip_ctx {
     size_t scratch_bytes = 0;
     void*  scratch2 = nullptr;
     size_t scratch2_bytes = 0;
+    // grow-only pinned host staging (results the kernels write straight into host memory: sfmhip_match_pairs)
+    void*  pinned = nullptr;
+    size_t pinned_bytes = 0;
     int    num_cus = 256;
     // optional per-kernel timing of the matching path (sfmhip_set_kernel_timing): event triples
     // [before kNN kernel, after it, after merge / re-score] for up to TIMING_SLOTS calls since the last query
@@ -102,6 +105,20 @@ static inline int sfm_scratch2(sfmhip_ctx* ctx, size_t bytes, void** out)
         ctx->scratch2_bytes = want;
     }
     *out = ctx->scratch2;
+    return SFMHIP_OK;
+}
+
+static inline int sfm_pinned(sfmhip_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->pinned_bytes) {
+        SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) SFM_HIP_TRY(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        SFM_HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
     return SFMHIP_OK;
 }
 

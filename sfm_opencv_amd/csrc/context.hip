@@ -45,6 +45,7 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& t : ctx->tev) for (auto& e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -1153,23 +1153,20 @@ int sfmhip_match_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets,
     SFM_RANGE("sfmhip_match_pairs");
     SFM_ARG_CHECK(ctx, ctx && matches_out && counts_out && max_per_pair > 0 && n_pairs >= 0);
     if (n_pairs == 0) return SFMHIP_OK;
-    sfm_dmatch* d_m = nullptr; int32_t* d_c = nullptr;
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&d_m, (size_t)n_pairs * max_per_pair * sizeof(sfm_dmatch)));
-    hipError_t e = hipMalloc((void**)&d_c, (size_t)n_pairs * sizeof(int32_t));
-    if (e != hipSuccess) { (void)hipFree(d_m); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
-    int rc = sfmhip_match_pairs_dev(ctx, sets, n_sets, pairs, n_pairs, ratio, floor_, mult, d_m, max_per_pair, d_c);
-    if (rc == SFMHIP_OK) {
-        e = hipMemcpyAsync(counts_out, d_c, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        for (int p = 0; p < n_pairs && e == hipSuccess; ++p)
-            if (counts_out[p] > 0)
-                e = hipMemcpyAsync(matches_out + (size_t)p * max_per_pair, d_m + (size_t)p * max_per_pair,
-                                   (size_t)counts_out[p] * sizeof(sfm_dmatch), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
+    // the ratio-tail kernel writes the lists and the counts straight into pinned host staging memory (only the surviving
+    // matches cross PCIe, no per-pair copies, no allocation per call); they are handed over with plain memcpys
+    void* stage = nullptr;
+    const size_t b_m = (size_t)n_pairs * max_per_pair * sizeof(sfm_dmatch), b_c = (size_t)n_pairs * sizeof(int32_t);
+    int rc = sfm_pinned(ctx, b_m + b_c, &stage); if (rc) return rc;
+    sfm_dmatch* h_m = (sfm_dmatch*)stage; int32_t* h_c = (int32_t*)((char*)stage + b_m);
+    rc = sfmhip_match_pairs_dev(ctx, sets, n_sets, pairs, n_pairs, ratio, floor_, mult, h_m, max_per_pair, h_c);
+    if (rc) return rc;
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < n_pairs; ++p) {
+        counts_out[p] = h_c[p];
+        if (h_c[p] > 0) memcpy(matches_out + (size_t)p * max_per_pair, h_m + (size_t)p * max_per_pair, (size_t)h_c[p] * sizeof(sfm_dmatch));
     }
-    (void)hipFree(d_m); (void)hipFree(d_c);
-    return rc;
+    return SFMHIP_OK;
 }
 
 static int knn2_host_common(sfmhip_ctx* ctx, sfmhip_descset* qs, sfmhip_descset* ts, int nq, int32_t* idx2, float* dist2)

@@ -191,3 +191,23 @@ def test_exact_sqrt_all_integers(ctx):
     n = C.c_int(-1)
     assert ctx.lib.sfmhip_selftest_exact_sqrt(ctx.h, C.byref(n)) == 0
     assert n.value == 0
+
+
+def test_match_lists_written_straight_to_pinned_host_memory(ctx):
+    """sfmhip_match_pairs_dev takes any device-accessible address: with pinned host tensors the ratio-tail kernel delivers the
+    match lists without a copy (what bench.py does).  Same lists as through device buffers."""
+    import torch
+    descs = synth.sift_descriptor_chain(4, 700, seed=46)
+    sets = [ctx.descset_l2(torch.from_numpy(d).cuda()) for d in descs]
+    pairs = np.array([[0, 1], [1, 2], [2, 3]], np.int32)
+    d_m = torch.zeros((3, 700, 4), dtype=torch.int32, device="cuda"); d_c = torch.zeros((3,), dtype=torch.int32, device="cuda")
+    h_m = torch.zeros((3, 700, 4), dtype=torch.int32).pin_memory(); h_c = torch.zeros((3,), dtype=torch.int32).pin_memory()
+    ctx.match_pairs_dev(sets, pairs, d_m, 700, d_c)
+    ctx.match_pairs_dev(sets, pairs, h_m, 700, h_c)
+    ctx.synchronize()
+    cnt = d_c.cpu().numpy()
+    assert (cnt > 100).all() and np.array_equal(cnt, h_c.numpy())
+    for p in range(3):
+        assert np.array_equal(d_m[p, :cnt[p]].cpu().numpy(), h_m[p, :cnt[p]].numpy())
+        m = orc.match_features_l2(descs[p], descs[p + 1])
+        assert np.array_equal(h_m[p, :cnt[p], 0].numpy(), m["queryIdx"]) and np.array_equal(h_m[p, :cnt[p], 1].numpy(), m["trainIdx"])
