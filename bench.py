@@ -298,6 +298,11 @@ def main():
                                   if (dom in RECORDED_TRAFFIC and world == 1 and args.config == "C4") else None,
                 "algorithmic_bytes": kd["bytes"], "avg_launch_ms": kd["ms"], "bytes_model": kd["what"],
                 "gather_bytes_requested": kd["gather"],
+                # what actually bounds the shared linearisation launch: fp64 VALU issue (SQ_INSTS_VALU of a separate --pmc pass; 4 cycles
+                # per wave instruction on 1,024 SIMDs at the 2.1 GHz the kernel runs at) -- recorded, C4 only
+                "valu_issue": ({"wave_instructions": 2.644e7, "frac_of_issue_slots": 2.644e7 * 4 / (1024 * 2.1e9 * kd["ms"] * 1e-3),
+                                "source": "profiles/r02_traffic_pmc.md (recorded by a separate --pmc pass, not measured in this run)"}
+                               if (dom == "ba_camschur_kernel" and world == 1 and args.config == "C4") else None),
                 "note": f"largest kernel of one LM iteration (the region `value` is measured on); the iteration is latency-bound at this size "
                         f"({phase[3]:.3f} ms of device time for {b_it / 1e6:.0f} MB), see roofline_lm_iteration and DESIGN.md 7"}
         roof_knn = None
