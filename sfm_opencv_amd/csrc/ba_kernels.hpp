@@ -960,9 +960,11 @@ __global__ void ba_publish_kernel(const double* __restrict__ scal2, const double
 struct BackCam { const double *pre, *t, *pre_c, *t_c, *sc, *y; };     // one camera's inputs of K_back (LDS record or global arrays)
 
 // body of K_back for one point; cam_at(c) -> BackCam
+#define BACK_ESAVE 8      // observations per point whose (E y) pair the first pass parks in LDS for the second (longer tracks re-derive it)
 template <typename CamAt>
-__device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_at, double acc[4])
+__device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_at, double acc[4], double (*esave)[256][2])
 {
+    const int tid = threadIdx.x;
     const double X[3] = { P.pts[3 * p], P.pts[3 * p + 1], P.pts[3 * p + 2] };
     const double sp[3] = { P.scale_p[3 * p], P.scale_p[3 * p + 1], P.scale_p[3 * p + 2] };
     double t[3] = { P.bp[3 * (size_t)p], P.bp[3 * (size_t)p + 1], P.bp[3 * (size_t)p + 2] };
@@ -987,6 +989,7 @@ __device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_a
         for (int j = 0; j < 4; ++j) { e0 += o.EK[0][j] * yK[j]; e1 += o.EK[1][j] * yK[j]; }
 #pragma unroll
         for (int j = 0; j < 3; ++j) t[j] -= o.F[0][j] * e0 + o.F[1][j] * e1;
+        if (k - s0 < BACK_ESAVE) { esave[k - s0][tid][0] = e0; esave[k - s0][tid][1] = e1; }
     }
     double yp[3];
     symv3(Vi, t, yp);
@@ -1000,13 +1003,20 @@ __device__ __forceinline__ void ba_back_point(const BADev& P, int p, CamAt cam_a
         const bool free_cam = cam_off(P, c) >= 0;
         const BackCam rec = cam_at(c);
         ObsLin o;
-        obs_linearize(P.K, rec.pre, rec.t, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, free_cam ? rec.sc : nullptr, sp, o);
         double m0 = 0.0, m1 = 0.0;
-        if (free_cam)
+        if (k - s0 < BACK_ESAVE) {
+            // the camera / intrinsic part of the model step is -(E y) of the first pass (the same sums in the same order, so the
+            // same bits): only r and F are re-derived here, without the 2 x 10 camera-side Jacobian
+            obs_linearize(P.K, rec.pre, rec.t, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, nullptr, nullptr, sp, o);
+            m0 = -esave[k - s0][tid][0]; m1 = -esave[k - s0][tid][1];
+        } else {
+            obs_linearize(P.K, rec.pre, rec.t, X, P.ouv[2 * k], P.ouv[2 * k + 1], P.huber_a, sK, free_cam ? rec.sc : nullptr, sp, o);
+            if (free_cam)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { const double yy = rec.y[j]; m0 -= o.Ec[0][j] * yy; m1 -= o.Ec[1][j] * yy; }
+                for (int j = 0; j < 6; ++j) { const double yy = rec.y[j]; m0 -= o.Ec[0][j] * yy; m1 -= o.Ec[1][j] * yy; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { m0 -= o.EK[0][j] * yK[j]; m1 -= o.EK[1][j] * yK[j]; }
+            for (int j = 0; j < 4; ++j) { m0 -= o.EK[0][j] * yK[j]; m1 -= o.EK[1][j] * yK[j]; }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) { m0 -= o.F[0][j] * yp[j]; m1 -= o.F[1][j] * yp[j]; }
         acc[0] -= m0 * (o.r[0] + 0.5 * m0) + m1 * (o.r[1] + 0.5 * m1);
@@ -1035,6 +1045,7 @@ __global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P, int n_pt_block
 {
     __shared__ double red[4][4];
     __shared__ __attribute__((aligned(16))) double cam[BACK_NCL][BACK_REC];
+    __shared__ double esave[BACK_ESAVE][256][2];
     if ((int)blockIdx.x >= n_pt_blocks) {
         const size_t zb = blockIdx.x - n_pt_blocks, nzb = gridDim.x - n_pt_blocks;
         const size_t total2 = (n0 + n1) / 2, per = (total2 + nzb - 1) / nzb, h0 = n0 / 2;
@@ -1060,12 +1071,12 @@ __global__ __launch_bounds__(256, 3) void ba_back_kernel(BADev P, int n_pt_block
         if (staged) {
             ba_back_point(P, p, [&](int c) {
                 const double* r = &cam[c - cmin][0];
-                return BackCam{ r, r + 20, r + 23, r + 43, r + 46, r + 52 }; }, acc);
+                return BackCam{ r, r + 20, r + 23, r + 43, r + 46, r + 52 }; }, acc, esave);
         } else {            // the block's points span too many cameras: straight from the global arrays
             ba_back_point(P, p, [&](int c) {
                 const int co = cam_off(P, c);
                 return BackCam{ P.campre + CAMPRE * (size_t)c, P.ext + 6 * c + 3, P.campre_c + CAMPRE * (size_t)c, P.extc + 6 * c + 3,
-                                P.scale_c + (co < 0 ? 0 : co), P.y + (co < 0 ? 0 : co) }; }, acc);
+                                P.scale_c + (co < 0 ? 0 : co), P.y + (co < 0 ? 0 : co) }; }, acc, esave);
         }
     }
 #pragma unroll
