@@ -549,25 +549,27 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
             const double q00 = 1.0 - (G[0][0] * o.F[0][0] + G[0][1] * o.F[0][1] + G[0][2] * o.F[0][2]);
             const double q01 = -(G[0][0] * o.F[1][0] + G[0][1] * o.F[1][1] + G[0][2] * o.F[1][2]);
             const double q11 = 1.0 - (G[1][0] * o.F[1][0] + G[1][1] * o.F[1][1] + G[1][2] * o.F[1][2]);
+            // Ec[1][3] and Ec[0][4] are exactly zero (the x / y translation columns touch one residual row each): their products
+            // are skipped -- fma(0, finite, acc) == acc, so the sums keep their bits
             double N0[6], N1[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                N0[j] = q00 * o.Ec[0][j] + q01 * o.Ec[1][j];
-                N1[j] = q01 * o.Ec[0][j] + q11 * o.Ec[1][j];
+                N0[j] = j == 4 ? q01 * o.Ec[1][j] : j == 3 ? q00 * o.Ec[0][j] : q00 * o.Ec[0][j] + q01 * o.Ec[1][j];
+                N1[j] = j == 4 ? q11 * o.Ec[1][j] : j == 3 ? q01 * o.Ec[0][j] : q01 * o.Ec[0][j] + q11 * o.Ec[1][j];
             }
             int a = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) { acc[a] = fma(o.Ec[0][i], N0[j], acc[a]); acc[a] = fma(o.Ec[1][i], N1[j], acc[a]); ++a; }
+                for (int j = 0; j <= i; ++j) { if (i != 4) acc[a] = fma(o.Ec[0][i], N0[j], acc[a]); if (i != 3) acc[a] = fma(o.Ec[1][i], N1[j], acc[a]); ++a; }
             const double r0 = o.r[0] - (G[0][0] * b[0] + G[0][1] * b[1] + G[0][2] * b[2]);
             const double r1 = o.r[1] - (G[1][0] * b[0] + G[1][1] * b[1] + G[1][2] * b[2]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { acc[45 + i] = fma(o.Ec[0][i], r0, acc[45 + i]); acc[45 + i] = fma(o.Ec[1][i], r1, acc[45 + i]); }
+            for (int i = 0; i < 6; ++i) { if (i != 4) acc[45 + i] = fma(o.Ec[0][i], r0, acc[45 + i]); if (i != 3) acc[45 + i] = fma(o.Ec[1][i], r1, acc[45 + i]); }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { acc[65 + i] = fma(o.Ec[0][i], o.Ec[0][i], acc[65 + i]); acc[65 + i] = fma(o.Ec[1][i], o.Ec[1][i], acc[65 + i]); }
+            for (int i = 0; i < 6; ++i) { if (i != 4) acc[65 + i] = fma(o.Ec[0][i], o.Ec[0][i], acc[65 + i]); if (i != 3) acc[65 + i] = fma(o.Ec[1][i], o.Ec[1][i], acc[65 + i]); }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { acc[71 + i] = fma(o.Ec[0][i], o.r[0], acc[71 + i]); acc[71 + i] = fma(o.Ec[1][i], o.r[1], acc[71 + i]); }
+            for (int i = 0; i < 6; ++i) { if (i != 4) acc[71 + i] = fma(o.Ec[0][i], o.r[0], acc[71 + i]); if (i != 3) acc[71 + i] = fma(o.Ec[1][i], o.r[1], acc[71 + i]); }
         } else {
             double WK[12];
 #pragma unroll
@@ -582,7 +584,7 @@ __device__ __forceinline__ void ba_camera_body(const BADev& P, double (*red)[CAM
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[a] = fma(o.Ec[0][i], H0[j], acc[a]); acc[a] = fma(o.Ec[1][i], H1[j], acc[a]); ++a; }
+                for (int j = 0; j < 4; ++j) { if (i != 4) acc[a] = fma(o.Ec[0][i], H0[j], acc[a]); if (i != 3) acc[a] = fma(o.Ec[1][i], H1[j], acc[a]); ++a; }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -749,15 +751,15 @@ __device__ __forceinline__ void ba_schur_role(const BADev& P, const int4* __rest
             const double m10 = G[1][0] * o.F[0][0] + G[1][1] * o.F[0][1] + G[1][2] * o.F[0][2];
             const double m11 = G[1][0] * o.F[1][0] + G[1][1] * o.F[1][1] + G[1][2] * o.F[1][2];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                N0[j] = m00 * o.Ec[0][j] + m01 * o.Ec[1][j];
-                N1[j] = m10 * o.Ec[0][j] + m11 * o.Ec[1][j];
+            for (int j = 0; j < 6; ++j) {          // Ec[1][3] == Ec[0][4] == 0 exactly (see ba_camera_body): those products are skipped
+                N0[j] = j == 4 ? m01 * o.Ec[1][j] : j == 3 ? m00 * o.Ec[0][j] : m00 * o.Ec[0][j] + m01 * o.Ec[1][j];
+                N1[j] = j == 4 ? m11 * o.Ec[1][j] : j == 3 ? m10 * o.Ec[0][j] : m10 * o.Ec[0][j] + m11 * o.Ec[1][j];
             }
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { acc[6 * i + j] = fma(Ea[0][i], N0[j], acc[6 * i + j]); acc[6 * i + j] = fma(Ea[1][i], N1[j], acc[6 * i + j]); }
+            for (int j = 0; j < 6; ++j) { if (i != 4) acc[6 * i + j] = fma(Ea[0][i], N0[j], acc[6 * i + j]); if (i != 3) acc[6 * i + j] = fma(Ea[1][i], N1[j], acc[6 * i + j]); }
     }
     const double tot = wave_reduce_scatter(acc, lane);
     const int e = wave_scatter_index(lane);
