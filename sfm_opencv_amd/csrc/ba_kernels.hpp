@@ -650,32 +650,28 @@ __device__ __forceinline__ void ba_finalize_role(const BADev& P, int n_pt_blocks
         }
         return;
     }
-    // intrinsic block + scalars
-    double acc[30];
+    // intrinsic block + scalars: thread (value i = tid & 31, slice = tid >> 5) sums value i over the point blocks of its slice --
+    // a wave reads whole 256-byte records, no cross-lane step -- then the eight slices are folded in a fixed order
+    {
+        __shared__ double red[8][32];
+        const int i = tid & 31, slice = tid >> 5;
+        double a = 0.0;
+        for (int b0 = slice; b0 < n_pt_blocks; b0 += 8 * 16) {      // sixteen records in flight per thread, folded in order
+            double v[16];
 #pragma unroll
-    for (int i = 0; i < 30; ++i) acc[i] = 0.0;
-    for (int b = tid; b < n_pt_blocks; b += 256) {
+            for (int u = 0; u < 16; ++u) { const int b = b0 + 8 * u; v[u] = b < n_pt_blocks ? P.part_pt[32 * (size_t)b + i] : (i == 15 ? 0.0 : 0.0); }
 #pragma unroll
-        for (int i = 0; i < 30; ++i) {
-            const double v = P.part_pt[32 * (size_t)b + i];
-            acc[i] = (i == 15) ? fmax(acc[i], v) : acc[i] + v;
+            for (int u = 0; u < 16; ++u) a = (i == 15) ? fmax(a, v[u]) : a + v[u];
         }
+        red[slice][i] = a;
+        __syncthreads();
+        if (tid < 30) {
+            double v = red[0][tid];
+            for (int w = 1; w < 8; ++w) v = (tid == 15) ? fmax(v, red[w][tid]) : v + red[w][tid];
+            sh[tid] = v;
+        }
+        __syncthreads();
     }
-    __shared__ double red[4][32];
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < 30; ++i) acc[i] = (i == 15) ? wave_max(acc[i]) : wave_sum(acc[i]);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 30; ++i) red[wave][i] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 30) {
-        double v = red[0][tid];
-        for (int w = 1; w < 4; ++w) v = (tid == 15) ? fmax(v, red[w][tid]) : v + red[w][tid];
-        sh[tid] = v;
-    }
-    __syncthreads();
     if (tid == 0) {
         P.scal[SCAL_COST] = sh[0];
         P.scal[SCAL_GMAX_SLOTS + P.rank] = sh[15];
