@@ -98,7 +98,9 @@ inline Gray blur(const Gray& src, double sigma)
     double s = 0;
     for (int i = -r; i <= r; ++i) { k[i + r] = (float)std::exp(-0.5 * i * i / (sigma * sigma)); s += k[i + r]; }
     for (float& v : k) v = (float)(v / s);
-    Gray tmp = src, dst = src;
+    Gray tmp, dst;
+    tmp.rows = dst.rows = src.rows; tmp.cols = dst.cols = src.cols;
+    tmp.v.resize(src.v.size()); dst.v.resize(src.v.size());
     const int W = src.cols, H = src.rows;
     for (int y = 0; y < H; ++y) {
         const float* row = &src.v[(size_t)y * W];
