@@ -328,7 +328,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img_match - 1} chain pairs matched), "
                                    f"{n_img} cameras / {n_pt} points / {n_obs} observations BA",
-                       "parallelism": f"points+pairs sharded over {world} rank(s), cameras replicated, 1 all-reduce/iteration",
+                       "parallelism": f"points+pairs sharded over {world} rank(s), cameras replicated, 2 all-reduces/iteration (packed reduced-system message + 5 step scalars)",
                        "reduced_system_order": n_red},
             "roofline": roof,
             "roofline_lm_iteration": {"bound": "hbm", "achieved": b_it / (phase[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
