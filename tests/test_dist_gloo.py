@@ -125,3 +125,25 @@ def test_two_processes_drive_libsfmhip_over_gloo(ctx, tmp_path, shape):
         assert np.abs(g["ext"] - extr).max() <= 1e-9 and np.abs(g["K"] - Kr).max() <= 1e-9 * np.abs(Kr).max()
         assert np.abs(g["pts"] - ptsr[g["ids"]]).max() <= 1e-9
         print(f"[gloo rehearsal {shape}] rank {r}: {float(g['ms']):.3f} ms per LM iteration with two processes on one card")
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_reports_one_line(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent spawns the two ranks (here sharing one card over gloo, the rehearsal
+    knobs of dist.py), rank 0 prints ONE JSON line with n_gpus = 2, strong scaling, and the whole-job figures."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFM_DIST_BACKEND="gloo", SFM_LOCAL_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "6", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-gemm"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["metric"] == "ba_iterations_per_sec"
+    assert d["value"] > 0 and d["ba_cost"]["after_timed_steps"] < d["ba_cost"]["initial"]
+    assert d["matched_pairs_per_sec"]["value"] > 0 and d["cpu_baseline"] is None
