@@ -147,3 +147,26 @@ def test_bench_starts_its_own_ranks_and_reports_one_line(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["metric"] == "ba_iterations_per_sec"
     assert d["value"] > 0 and d["ba_cost"]["after_timed_steps"] < d["ba_cost"]["initial"]
     assert d["matched_pairs_per_sec"]["value"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_under_the_drivers_launcher(tmp_path):
+    """The way the driver starts N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) -- here two ranks on one
+    card over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SFM_DIST_BACKEND="gloo", SFM_LOCAL_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "6",
+                          "--warmup", "2", "--no-cpu-baseline", "--no-gemm"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["matched_pairs_per_sec"]["value"] > 0
