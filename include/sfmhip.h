@@ -209,7 +209,10 @@ typedef struct {
     double final_cost;
     double final_radius;
     double final_gradient_max_norm;
-    double total_time_s;
+    double total_time_s;          /* the whole call (ceres::Solver::Summary::total_time_in_seconds, the "Time (s)" of NView:1239) */
+    double preprocessor_time_s;   /* sfmhip_ba_solve: problem construction (uploads, orderings, pair lists) + solver plan + scaling */
+    double minimizer_time_s;      /* the LM loop */
+    double postprocessor_time_s;  /* sfmhip_ba_solve: parameters back into the caller's arrays + teardown */
 } sfm_ba_summary;
 
 void sfmhip_ba_default_options(sfm_ba_options* o);
@@ -246,6 +249,13 @@ int  sfmhip_ba_get_params(sfmhip_ba*, double* intrinsic4, double* ext6, double* 
  * both triangles filled; rhs n) after the all-reduce.  Either pointer may be NULL.  radius < 0: the points are
  * damped with |radius| but the camera-side damping is skipped, so the result is additive over point shards. */
 int  sfmhip_ba_reduced_system(sfmhip_ba*, double radius, double* S, double* rhs, int* n, double* cost);
+/* Test/diagnostic: copy out one of the tables sfmhip_ba_create builds on the device (NView:1187-1210 is where the reference
+ * hands the same observation list to ceres::Problem): "pt_slot" (caller's point -> storage slot), "pt_start", "ocam", "opt",
+ * "ouv" (observations by slot, then camera), "cam_start", "cam_pt", "cam_uv" (camera-ordered copy), "blk_crange", "blk_cam",
+ * "blk_chunk", "chunk_desc", "items" (camera-pair lists; int32 except the double pixel arrays), "setup_ms" (4 doubles: host
+ * clock of sfmhip_ba_create, cumulative: inputs + observation sort, + orderings, + pair lists, whole call).
+ * out == NULL: only *n_bytes is set.  Synchronises. */
+int  sfmhip_ba_debug_table(sfmhip_ba*, const char* name, void* out, size_t cap_bytes, size_t* n_bytes);
 /* average device time (ms) per LM iteration of the last sfmhip_ba_iterate call, measured with HIP events on the
  * context's stream WHILE sfmhip_set_kernel_timing(ctx, 1) is in effect (all zero otherwise: the thirteen event records
  * cost ~27 us per iteration, so they are off by default): [0]=linearise+Schur build, [1]=reduced solve, [2]=back-substitution+cost, [3]=total,

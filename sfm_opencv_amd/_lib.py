@@ -31,7 +31,8 @@ class BASummary(C.Structure):
     _fields_ = [("termination", C.c_int), ("iterations", C.c_int), ("successful_steps", C.c_int),
                 ("num_residuals", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("final_radius", C.c_double), ("final_gradient_max_norm", C.c_double),
-                ("total_time_s", C.c_double)]
+                ("total_time_s", C.c_double), ("preprocessor_time_s", C.c_double),
+                ("minimizer_time_s", C.c_double), ("postprocessor_time_s", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -53,7 +54,7 @@ SYMBOLS = [
     "sfmhip_triangulate_tracks", "sfmhip_reprojection_errors",
     "sfmhip_ba_default_options", "sfmhip_ba_solve", "sfmhip_ba_create", "sfmhip_ba_destroy",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_run", "sfmhip_ba_iterate", "sfmhip_ba_reset",
-    "sfmhip_ba_get_params", "sfmhip_ba_reduced_system", "sfmhip_ba_phase_ms",
+    "sfmhip_ba_get_params", "sfmhip_ba_reduced_system", "sfmhip_ba_phase_ms", "sfmhip_ba_debug_table",
     "sfmhip_estimate_normals",
 ]
 
@@ -119,6 +120,7 @@ def load():
         "sfmhip_ba_get_params": (i32, [vp, vp, vp, vp]),
         "sfmhip_ba_reduced_system": (i32, [vp, f64, vp, vp, C.POINTER(i32), C.POINTER(f64)]),
         "sfmhip_ba_phase_ms": (i32, [vp, C.POINTER(f64)]),
+        "sfmhip_ba_debug_table": (i32, [vp, C.c_char_p, vp, sz, C.POINTER(sz)]),
         "sfmhip_estimate_normals": (i32, [vp, vp, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():

@@ -301,6 +301,17 @@ class BAProblem:
         self.ctx._check(self.ctx.lib.sfmhip_ba_reduced_system(self.h, radius, S.ctypes.data, rhs.ctypes.data, C.byref(n), C.byref(cost)))
         return S, rhs, cost.value
 
+    _TABLE_DTYPES = {"ouv": np.float64, "cam_uv": np.float64, "setup_ms": np.float64}
+
+    def debug_table(self, name):
+        """One of the tables sfmhip_ba_create built on the device (sfmhip_ba_debug_table), as a numpy array."""
+        nb = C.c_size_t()
+        self.ctx._check(self.ctx.lib.sfmhip_ba_debug_table(self.h, name.encode(), None, 0, C.byref(nb)))
+        dt = np.dtype(self._TABLE_DTYPES.get(name, np.int32))
+        out = np.empty(nb.value // dt.itemsize, dt)
+        self.ctx._check(self.ctx.lib.sfmhip_ba_debug_table(self.h, name.encode(), out.ctypes.data, out.nbytes, C.byref(nb)))
+        return out
+
     def phase_ms(self):
         out = (C.c_double * 8)()
         self.ctx._check(self.ctx.lib.sfmhip_ba_phase_ms(self.h, out))

@@ -37,7 +37,7 @@ def test_release_build_has_no_experiment_knobs():
 
 def test_struct_layouts_match_the_header():
     assert api.DMATCH.itemsize == 16 and api.KEYPOINT.itemsize == 28
-    assert C.sizeof(_lib.BAOptions) == 112 and C.sizeof(_lib.BASummary) == 56
+    assert C.sizeof(_lib.BAOptions) == 112 and C.sizeof(_lib.BASummary) == 80
     o = _lib.BAOptions(); _lib.load().sfmhip_ba_default_options(C.byref(o))
     assert (o.max_num_iterations, o.huber_delta, o.initial_trust_region_radius, o.fix_first_camera, o.fix_intrinsics) == (50, 4.0, 1e4, 1, 0)
 
