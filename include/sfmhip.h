@@ -53,6 +53,10 @@ void sfmhip_destroy(sfmhip_ctx* ctx);
 /* enqueue on an external stream (e.g. torch's current stream); NULL = the context's own stream */
 int  sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream);
 int  sfmhip_synchronize(sfmhip_ctx* ctx);
+/* The context keeps the device memory of destroyed bundle-adjustment problems (and the temporaries of their construction) for
+ * the next one: handing gigabytes back to the driver stalls the following HIP calls for ~0.1 s.  sfmhip_trim releases what is
+ * idle (sfmhip_destroy releases everything).  No reference counterpart. */
+int  sfmhip_trim(sfmhip_ctx* ctx);
 /* Measurement aid (no reference counterpart): with timing enabled every kNN launch sequence on this context is
  * bracketed by HIP events on its stream.  sfmhip_match_kernel_ms synchronises and returns, averaged over the calls
  * since the last query (at most 64): [0] the kNN kernel itself (knn2_i8 / exact f32 / hamming2), [1] merge + re-score,

@@ -42,7 +42,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/sfmhip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sfmhip_create", "sfmhip_destroy", "sfmhip_set_stream", "sfmhip_synchronize", "sfmhip_last_error",
+    "sfmhip_create", "sfmhip_destroy", "sfmhip_set_stream", "sfmhip_synchronize", "sfmhip_trim", "sfmhip_last_error",
     "sfmhip_version", "sfmhip_set_kernel_timing", "sfmhip_match_kernel_ms",
     "sfmhip_descset_create_l2_host", "sfmhip_descset_create_l2_dev",
     "sfmhip_descset_create_hamming2_host", "sfmhip_descset_create_hamming2_dev",
@@ -82,6 +82,7 @@ def load():
         "sfmhip_destroy": (None, [vp]),
         "sfmhip_set_stream": (i32, [vp, vp]),
         "sfmhip_synchronize": (i32, [vp]),
+        "sfmhip_trim": (i32, [vp]),
         "sfmhip_last_error": (C.c_char_p, [vp]),
         "sfmhip_version": (C.c_char_p, []),
         "sfmhip_set_kernel_timing": (i32, [vp, i32]),

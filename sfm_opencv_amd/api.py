@@ -84,6 +84,10 @@ class Context:
     def synchronize(self):
         self._check(self.lib.sfmhip_synchronize(self.h))
 
+    def trim(self):
+        """release the device blocks the context keeps from destroyed BA problems (sfmhip_trim)"""
+        self._check(self.lib.sfmhip_trim(self.h))
+
     def set_kernel_timing(self, enable=True):
         """bracket every kNN launch sequence with HIP events (sfmhip_set_kernel_timing)"""
         self._check(self.lib.sfmhip_set_kernel_timing(self.h, 1 if enable else 0))

@@ -245,12 +245,12 @@ static int dalloc(sfmhip_ba* h, T** p, size_t count)
         const size_t chunk = std::max(h->arena_chunk, (size_t)1 << 20);
         void* q = nullptr;
         if (bytes >= chunk / 4) {           // large arrays get their own block, the arena keeps its room for the small ones
-            SFM_HIP_TRY(h->ctx, hipMalloc(&q, bytes));
+            int rc = sfm_pool_get(h->ctx, bytes, &q); if (rc) return rc;
             h->allocs.push_back(q);
             *p = (T*)q;
             return SFMHIP_OK;
         }
-        SFM_HIP_TRY(h->ctx, hipMalloc(&q, chunk));
+        int rc = sfm_pool_get(h->ctx, chunk, &q); if (rc) return rc;
         h->allocs.push_back(q);
         h->arena = (char*)q; h->arena_left = chunk;
     }
@@ -1074,15 +1074,15 @@ static void fill_summary(const sfmhip_ba* h, sfm_ba_summary* s, double t_s)
     s->preprocessor_time_s = h->start_ms * 1e-3; s->minimizer_time_s = t_s - h->start_ms * 1e-3; s->postprocessor_time_s = 0.0;
 }
 
-// Device temporaries of sfmhip_ba_create: freed when the builder goes out of scope (after the stream has drained).
+// Device temporaries of sfmhip_ba_create, out of the context's block cache.
 struct SetupTemps {
     sfmhip_ctx* ctx; std::vector<void*> blocks;
     explicit SetupTemps(sfmhip_ctx* c) : ctx(c) {}
-    ~SetupTemps() { if (!blocks.empty()) (void)hipStreamSynchronize(ctx->stream); for (void* p : blocks) (void)hipFree(p); }
+    ~SetupTemps() { for (void* p : blocks) sfm_pool_put(ctx, p); }       // stream-ordered reuse: back to the context's cache
     template <typename T> int get(T** p, size_t count)
     {
         void* q = nullptr;
-        SFM_HIP_TRY(ctx, hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T)));
+        int rc = sfm_pool_get(ctx, (count > 0 ? count : 1) * sizeof(T), &q); if (rc) return rc;
         blocks.push_back(q); *p = (T*)q;
         return SFMHIP_OK;
     }
@@ -1103,15 +1103,16 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     int rc = SFMHIP_OK;
 #define TRY_RC(x) do { rc = (x); if (rc) return rc; } while (0)
     const auto t0 = std::chrono::steady_clock::now();
+    // verbose >= 2: host clock at every step, each behind a stream sync (diagnostic; changes the overlap it measures)
+    auto stamp = [&](const char* what) { if (h->o.verbose >= 2) { (void)hipStreamSynchronize(st); printf("[sfmhip_ba setup] %-28s %8.3f ms\n", what, ms_since(t0)); } };
     // ---- raw inputs -> HBM
     int *d_rc = nullptr, *d_rp = nullptr; double *d_ruv = nullptr, *d_rpts = nullptr;
     TRY_RC(T.get(&d_rc, (size_t)nobs)); TRY_RC(T.get(&d_rp, (size_t)nobs)); TRY_RC(T.get(&d_ruv, 2 * (size_t)nobs)); TRY_RC(T.get(&d_rpts, 3 * (size_t)np));
-    if (nobs) {
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(d_rc, obs_cam, (size_t)nobs * sizeof(int), hipMemcpyHostToDevice, st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(d_rp, obs_pt, (size_t)nobs * sizeof(int), hipMemcpyHostToDevice, st));
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(d_ruv, obs_uv, 2 * (size_t)nobs * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    if (np) SFM_HIP_TRY(ctx, hipMemcpyAsync(d_rpts, pts, 3 * (size_t)np * sizeof(double), hipMemcpyHostToDevice, st));
+    stamp("input buffers");
+    // the two index arrays first: the observation sort runs while the pixels and the points are still on their way
+    TRY_RC(sfm_upload(ctx, d_rc, obs_cam, (size_t)nobs * sizeof(int)));
+    TRY_RC(sfm_upload(ctx, d_rp, obs_pt, (size_t)nobs * sizeof(int)));
+    stamp("index arrays uploaded");
     // ---- persistent tables
     TRY_RC(dalloc(h, &h->d_pt_start, (size_t)np + 1)); TRY_RC(dalloc(h, &h->d_ocam, (size_t)nobs)); TRY_RC(dalloc(h, &h->d_opt, (size_t)nobs));
     TRY_RC(dalloc(h, &h->d_ouv, 2 * (size_t)nobs)); TRY_RC(dalloc(h, &h->d_cam_start, (size_t)nc + 1)); TRY_RC(dalloc(h, &h->d_cam_pt, (size_t)nobs));
@@ -1119,32 +1120,32 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     TRY_RC(dalloc(h, &h->d_pts, 3 * (size_t)np)); TRY_RC(dalloc(h, &h->d_pts0, 3 * (size_t)np)); TRY_RC(dalloc(h, &h->d_ptsc, 3 * (size_t)np));
     // ---- temporaries of the observation / point phase
     const size_t nmax = (size_t)std::max(nobs, np);
-    su64 *obsK[2], *ptK[2]; su32 *obsV[2], *ptV[2], *cnt_pt, *cnt_cam, *st_pt, *hist, *bsum; int* d_flags; su64* d_total;
+    su64 *obsK[2], *ptK[2]; su32 *obsV[2], *ptV[2], *st_pt, *hist, *bsum; int* d_flags; su64* d_total;
     for (int i = 0; i < 2; ++i) { TRY_RC(T.get(&obsK[i], (size_t)nobs)); TRY_RC(T.get(&obsV[i], (size_t)nobs)); TRY_RC(T.get(&ptK[i], (size_t)np)); TRY_RC(T.get(&ptV[i], (size_t)np)); }
-    TRY_RC(T.get(&cnt_pt, (size_t)np + 1)); TRY_RC(T.get(&st_pt, (size_t)np + 1)); TRY_RC(T.get(&cnt_cam, (size_t)nc + 1));
+    TRY_RC(T.get(&st_pt, (size_t)np + 1));
     TRY_RC(T.get(&hist, 256 * setup_rs_tiles(nmax) + 1)); TRY_RC(T.get(&bsum, setup_scan_tiles(std::max(256 * setup_rs_tiles(nmax), nmax + 1)) + 1));
     TRY_RC(T.get(&d_flags, 4)); TRY_RC(T.get(&d_total, 2));
-    SFM_HIP_TRY(ctx, hipMemsetAsync(cnt_pt, 0, ((size_t)np + 1) * sizeof(su32), st));
-    SFM_HIP_TRY(ctx, hipMemsetAsync(cnt_cam, 0, ((size_t)nc + 1) * sizeof(su32), st));
     SFM_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(int), st));
+    stamp("tables + temporaries");
     const int cb = std::max(1, setup_bit_width((su64)nc - 1)), pb = std::max(1, setup_bit_width((su64)std::max(np, 1) - 1));
     const unsigned gobs = (unsigned)ceil_div(std::max(nobs, 1), 256), gpt = (unsigned)ceil_div(std::max(np, 1), 256);
     // ---- observations by (point, camera, caller's index)
     int ro = 0;
     if (nobs) {
-        hipLaunchKernelGGL(setup_obs_key_kernel, dim3(gobs), dim3(256), 0, st, (const int*)d_rc, (const int*)d_rp, nobs, nc, np, cb, obsK[0], cnt_pt, cnt_cam, d_flags);
+        hipLaunchKernelGGL(setup_obs_key_kernel, dim3(gobs), dim3(256), 0, st, (const int*)d_rc, (const int*)d_rp, nobs, nc, np, cb, obsK[0], d_flags);
         SetupSortBufs B = { { obsK[0], obsK[1] }, { obsV[0], obsV[1] }, hist, bsum };
         ro = setup_radix_sort(st, B, (size_t)nobs, cb + pb, true);
     }
-    if (np) hipLaunchKernelGGL(setup_max_kernel, dim3(gpt), dim3(256), 0, st, (const su32*)cnt_pt, np, (su32*)(d_flags + 1));
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(st_pt, cnt_pt, ((size_t)np + 1) * sizeof(su32), hipMemcpyDeviceToDevice, st));
-    setup_enqueue_scan(st, st_pt, (size_t)np + 1, bsum, nullptr);
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_cam_start, cnt_cam, ((size_t)nc + 1) * sizeof(su32), hipMemcpyDeviceToDevice, st));
-    setup_enqueue_scan(st, (su32*)h->d_cam_start, (size_t)nc + 1, bsum, nullptr);
+    // first observation of every point in the sorted list (no counters, no atomics: the run boundaries of the sorted keys), longest track
+    hipLaunchKernelGGL(setup_starts_kernel, dim3((unsigned)ceil_div(nobs + 1, 256)), dim3(256), 0, st, (const su64*)obsK[ro], (size_t)nobs, cb, (su64)np, st_pt);
+    hipLaunchKernelGGL(setup_max_kernel, dim3((unsigned)std::min(1024, (int)gpt)), dim3(256), 0, st, (const su32*)st_pt, np, (su32*)(d_flags + 1));
     int flags[4] = { 0, 0, 0, 0 };
-    std::vector<int> cam_start((size_t)nc + 1);
+    stamp("observation sort");
     SFM_HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(cam_start.data(), h->d_cam_start, cam_start.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    // behind the sort on the stream: the pixels and the points (the host fills the pinned staging buffers meanwhile)
+    TRY_RC(sfm_upload(ctx, d_ruv, obs_uv, 2 * (size_t)nobs * sizeof(double)));
+    TRY_RC(sfm_upload(ctx, d_rpts, pts, 3 * (size_t)np * sizeof(double)));
+    stamp("pixels + points uploaded");
     SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (flags[0]) { ctx->last_error = "bad argument: observation with a camera or point index out of range"; return SFMHIP_E_ARG; }
     h->setup_ms[0] = ms_since(t0);
@@ -1155,20 +1156,22 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
         for (int g = groups - 1; g >= 0 && np > 0; --g) {
             const int j0 = g * G, npos = std::min(G, mmax - j0);
             hipLaunchKernelGGL(setup_ptkey_kernel, dim3(gpt), dim3(256), 0, st, g == groups - 1 ? (const su32*)nullptr : (const su32*)V[0], np, (const su32*)st_pt,
-                               (const su32*)cnt_pt, (const su64*)obsK[ro], (1ull << cb) - 1ull, j0, npos, b, K[0]);
+                               (const su64*)obsK[ro], (1ull << cb) - 1ull, j0, npos, b, K[0]);
             SetupSortBufs B = { { K[0], K[1] }, { V[0], V[1] }, hist, bsum };
             if (setup_radix_sort(st, B, (size_t)np, npos * b, g == groups - 1)) { std::swap(K[0], K[1]); std::swap(V[0], V[1]); }
         }
         SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_pt_start, 0, ((size_t)np + 1) * sizeof(int), st));
-        if (np) hipLaunchKernelGGL(setup_slot_kernel, dim3(gpt), dim3(256), 0, st, (const su32*)V[0], np, (const su32*)cnt_pt, h->d_slot, (su32*)h->d_pt_start);
+        if (np) hipLaunchKernelGGL(setup_slot_kernel, dim3(gpt), dim3(256), 0, st, (const su32*)V[0], np, (const su32*)st_pt, h->d_slot, (su32*)h->d_pt_start);
         setup_enqueue_scan(st, (su32*)h->d_pt_start, (size_t)np + 1, bsum, nullptr);
     }
+    stamp("point sort");
     // ---- observations and points into storage order, the camera-ordered copy, the camera range of every 256 points
     if (nobs) {
         hipLaunchKernelGGL(setup_fill_obs_kernel, dim3(gobs), dim3(256), 0, st, (const su64*)obsK[ro], (const su32*)obsV[ro], nobs, cb, (const su32*)st_pt, (const int*)h->d_slot,
                            (const int*)h->d_pt_start, (const double2*)d_ruv, h->d_ocam, h->d_opt, (double2*)h->d_ouv, obsK[ro ^ 1]);
         SetupSortBufs B = { { obsK[ro ^ 1], obsK[ro] }, { obsV[ro ^ 1], obsV[ro] }, hist, bsum };
         const int r = setup_radix_sort(st, B, (size_t)nobs, cb, true);
+        hipLaunchKernelGGL(setup_starts_kernel, dim3((unsigned)ceil_div(nobs + 1, 256)), dim3(256), 0, st, (const su64*)B.k[r], (size_t)nobs, 0, (su64)nc, (su32*)h->d_cam_start);
         hipLaunchKernelGGL(setup_cam_copy_kernel, dim3(gobs), dim3(256), 0, st, (const su32*)B.v[r], nobs, (const int*)h->d_opt, (const double2*)h->d_ouv, h->d_cam_pt,
                            (double2*)h->d_cam_uv);
     }
@@ -1177,7 +1180,9 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_pts0, h->d_pts, 3 * (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, st));
         SFM_HIP_TRY(ctx, hipMemcpyAsync(h->d_ptsc, h->d_pts, 3 * (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
+    if (!nobs) SFM_HIP_TRY(ctx, hipMemsetAsync(h->d_cam_start, 0, ((size_t)nc + 1) * sizeof(int), st));
     hipLaunchKernelGGL(setup_crange_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, (const int*)h->d_pt_start, (const int*)h->d_ocam, np, h->d_blk_crange);
+    stamp("storage order + camera copy");
     // ---- camera-pair lists for the off-diagonal Schur blocks (and same-camera pairs)
     su32* npair = nullptr;
     TRY_RC(T.get(&npair, (size_t)np + 1));
@@ -1185,7 +1190,9 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     if (np) hipLaunchKernelGGL(setup_pair_count_kernel, dim3(gpt), dim3(256), 0, st, (const int*)h->d_pt_start, (const int*)h->d_ocam, np, h->fix0, npair);
     setup_enqueue_scan(st, npair, (size_t)np + 1, bsum, d_total);
     su64 total_pairs = 0;
+    std::vector<int> cam_start((size_t)nc + 1);
     SFM_HIP_TRY(ctx, hipMemcpyAsync(&total_pairs, d_total, sizeof(su64), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(cam_start.data(), h->d_cam_start, cam_start.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
     SFM_HIP_TRY(ctx, hipGetLastError());
     h->setup_ms[1] = ms_since(t0);
@@ -1204,8 +1211,10 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
         TRY_RC(T.get(&hist2, 256 * setup_rs_tiles(npairs) + 1)); TRY_RC(T.get(&bsum2, setup_scan_tiles(std::max(256 * setup_rs_tiles(npairs), npairs + 1)) + 1));
         hipLaunchKernelGGL(setup_pair_gen_kernel, dim3(gobs), dim3(256), 0, st, (const int*)h->d_pt_start, (const int*)h->d_ocam, (const int*)h->d_opt, nobs, h->fix0, nc,
                            (const su32*)npair, pK[0], raw);
+        stamp("pair generation");
         SetupSortBufs B = { { pK[0], pK[1] }, { pV[0], pV[1] }, hist2, bsum2 };
         const int r = setup_radix_sort(st, B, npairs, setup_bit_width((su64)nc * (su64)nc - 1), true);
+        stamp("pair sort");
         const unsigned gpair = (unsigned)((npairs + 1 + 255) / 256);
         hipLaunchKernelGGL(setup_flag_kernel, dim3(gpair), dim3(256), 0, st, (const su64*)pK[r], npairs, flag);
         setup_enqueue_scan(st, flag, npairs + 1, bsum2, d_total);
@@ -1244,6 +1253,7 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     TRY_RC(dupload(h, &h->d_blk_cam, blk_cam.data(), blk_cam.size())); TRY_RC(dupload(h, &h->d_blk_chunk, blk_chunk.data(), blk_chunk.size()));
     TRY_RC(dupload(h, &h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()));
     TRY_RC(dalloc(h, &h->d_part_schur, 36 * (size_t)h->nchunk));
+    stamp("pair lists");
     h->setup_ms[2] = ms_since(t0);
 
     int max_cam = 1;
@@ -1323,10 +1333,10 @@ void sfmhip_ba_destroy(sfmhip_ba* h)
     SFM_DEVICE_GUARD(h ? h->ctx : nullptr);
     if (!h) return;
     (void)hipStreamSynchronize(h->ctx->stream);
-    for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->allocs) sfm_pool_put(h->ctx, p);          // kept by the context for the next problem (sfmhip_trim releases them)
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->aux) (void)hipStreamSynchronize(h->aux);         // the stream itself belongs to the context
     for (auto& pr : h->evb) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     for (auto& pr : h->evi) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1391,8 +1401,11 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evb) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
     for (auto& pr : h->evi) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "hipEventCreate"; return SFMHIP_E_HIP; }
-    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) ctx->aux_stream = nullptr;
+    h->aux = ctx->aux_stream;
+    if (!h->aux || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "auxiliary stream"; return SFMHIP_E_HIP; }
+    if (h->o.verbose >= 2) printf("[sfmhip_ba setup] %-28s %8.3f ms\n", "work arrays, events", ms_since(t0));
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sfmhip_ba_destroy(h); ctx->last_error = "upload failed"; return SFMHIP_E_HIP; }
     h->setup_ms[3] = ms_since(t0);
     if (h->o.verbose)

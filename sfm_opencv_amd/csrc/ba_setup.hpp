@@ -203,50 +203,64 @@ static inline int setup_radix_sort(hipStream_t st, const SetupSortBufs& B, size_
 // ------------------------------------------------------------------------------------------------
 static inline int setup_bit_width(su64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
-// observation k -> key (point << cb | camera), per-point and per-camera counts; flags[0] |= 1 on an index out of range
+// observation k -> key (point << cb | camera); flags[0] |= 1 on an index out of range (the key then stays inside the tables)
 __global__ __launch_bounds__(256) void setup_obs_key_kernel(const int* __restrict__ rc, const int* __restrict__ rp, int nobs, int nc, int np, int cb,
-                                                            su64* __restrict__ keys, su32* __restrict__ cnt_pt, su32* __restrict__ cnt_cam, int* __restrict__ flags)
+                                                            su64* __restrict__ keys, int* __restrict__ flags)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nobs) return;
     const int c = rc[k], p = rp[k];
     if (c < 0 || c >= nc || p < 0 || p >= np) { atomicOr(flags, 1); keys[k] = 0; return; }
     keys[k] = ((su64)p << cb) | (su64)c;
-    atomicAdd(&cnt_pt[p], 1u);
-    atomicAdd(&cnt_cam[c], 1u);
 }
 
-__global__ __launch_bounds__(256) void setup_max_kernel(const su32* __restrict__ v, int n, su32* __restrict__ out)
+// keys sorted; v(i) = keys[i] >> shift < nvals.  starts[v] = first i with v(i) >= v, for v = 0 .. nvals (starts[nvals] = n): the
+// CSR offsets of the sorted list without counters or atomics (an atomic per observation on its camera's counter -- 8,000 per
+// address at C5 -- made this pass 10 ms; as boundaries of the sorted keys it is one coalesced read)
+__global__ __launch_bounds__(256) void setup_starts_kernel(const su64* __restrict__ keys, size_t n, int shift, su64 nvals, su32* __restrict__ starts)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    su32 x = i < n ? v[i] : 0u;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    const su64 cur = i < n ? keys[i] >> shift : nvals;
+    su64 v = i > 0 ? (keys[i - 1] >> shift) + 1 : 0;
+    for (; v <= cur && v <= nvals; ++v) starts[v] = (su32)i;
+}
+
+// max over p of st[p + 1] - st[p] (the longest track): one atomic per workgroup
+__global__ __launch_bounds__(256) void setup_max_kernel(const su32* __restrict__ st, int n, su32* __restrict__ out)
+{
+    __shared__ su32 sm[4];
+    su32 x = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x = max(x, st[i + 1] - st[i]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x = max(x, (su32)__shfl_xor(x, off));
-    if ((threadIdx.x & 63) == 0 && x) atomicMax(out, x);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) { x = max(max(sm[0], sm[1]), max(sm[2], sm[3])); if (x) atomicMax(out, x); }
 }
 
 // Sort key of a point for one group of positions [j0, j0 + npos) of its ascending camera list: fields of b bits,
 // earlier positions in the higher bits, camera + 1 (0 = the list has ended: a prefix sorts first).
-__global__ __launch_bounds__(256) void setup_ptkey_kernel(const su32* __restrict__ order, int np, const su32* __restrict__ st, const su32* __restrict__ cnt,
+__global__ __launch_bounds__(256) void setup_ptkey_kernel(const su32* __restrict__ order, int np, const su32* __restrict__ st,
                                                           const su64* __restrict__ obs_keys, su64 cam_mask, int j0, int npos, int b, su64* __restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= np) return;
     const su32 p = order ? order[i] : (su32)i;
-    const su32 base = st[p], m = cnt[p];
+    const su32 base = st[p], m = st[p + 1] - base;
     su64 key = 0;
     for (int j = j0; j < j0 + npos; ++j) key = (key << b) | ((su32)j < m ? (obs_keys[base + j] & cam_mask) + 1ull : 0ull);
     out[i] = key;
 }
 
 // slot of every point, and the per-slot observation counts (scanned into pt_start by the caller)
-__global__ __launch_bounds__(256) void setup_slot_kernel(const su32* __restrict__ order, int np, const su32* __restrict__ cnt, int* __restrict__ slot,
+__global__ __launch_bounds__(256) void setup_slot_kernel(const su32* __restrict__ order, int np, const su32* __restrict__ st, int* __restrict__ slot,
                                                          su32* __restrict__ cnt_slot)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= np) return;
     const su32 p = order[s];
-    slot[p] = s; cnt_slot[s] = cnt[p];
+    slot[p] = s; cnt_slot[s] = st[p + 1] - st[p];
 }
 
 // observations into their final order: by slot, inside a point by (camera, caller's index)

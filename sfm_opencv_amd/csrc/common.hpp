@@ -1,6 +1,7 @@
 // common.hpp -- internal definitions shared by the translation units of libsfmhip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +23,22 @@ struct sfmhip_ctx {
     // grow-only pinned host staging (results the kernels write straight into host memory: sfmhip_match_pairs)
     void*  pinned = nullptr;
     size_t pinned_bytes = 0;
+    // pinned staging ring for large uploads from the caller's pageable memory (sfm_upload, context.hip)
+    static constexpr size_t STAGE_BYTES = (size_t)16 << 20;
+    void*  stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_ev[2] = { nullptr, nullptr };
+    bool   stage_busy[2] = { false, false };
+    int    stage_next = 0;
+    // Cache of device blocks (sfm_pool_get / sfm_pool_put): the arrays and the construction temporaries of bundle-adjustment
+    // problems.  Giving gigabytes back to the driver costs ~0.1 s that surfaces in whatever HIP call comes next (measured: the
+    // second sfmhip_ba_create at C5 took 127 ms against 13 ms for the first), so freed blocks are kept and handed out again;
+    // sfmhip_trim / sfmhip_destroy release them.
+    struct PoolBlock { void* p; size_t bytes; bool used; };
+    std::vector<PoolBlock> pool;
+    size_t pool_idle_bytes = 0;
+    static constexpr size_t POOL_IDLE_CAP = (size_t)48 << 30;      // idle bytes kept at most (of 288 GB)
+    // second stream of the bundle-adjustment problems (created on first use and kept: a hipStreamCreate costs milliseconds)
+    hipStream_t aux_stream = nullptr;
     int    num_cus = 256;
     // optional per-kernel timing of the matching path (sfmhip_set_kernel_timing): event triples
     // [before kNN kernel, after it, after merge / re-score] for up to TIMING_SLOTS calls since the last query
@@ -121,6 +138,17 @@ static inline int sfm_pinned(sfmhip_ctx* ctx, size_t bytes, void** out)
     *out = ctx->pinned;
     return SFMHIP_OK;
 }
+
+// Host -> HBM copy of a caller's (pageable) array, ordered on the context's stream.  hipMemcpyAsync from pageable memory runs at
+// 9-13 GB/s on the MI355X boxes (one runtime thread staging); above 4 MB this goes through two pinned 16 MB buffers filled by four
+// host threads instead (43 GB/s, experiments/h2d_bench.hip).  The source may be reused as soon as the call returns.
+int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+// device block of at least `bytes` from the context's cache (an idle block of up to 4x the size, else a new hipMalloc); stream-ordered
+// reuse: every user of these blocks works on the context's stream
+int  sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out);
+void sfm_pool_put(sfmhip_ctx* ctx, void* p);
+void sfm_pool_trim(sfmhip_ctx* ctx);
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int x, int m) { return (x + m - 1) / m; }

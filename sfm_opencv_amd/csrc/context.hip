@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <cfloat>
 #include <dlfcn.h>
+#include <thread>
 
 SfmRoctx::SfmRoctx()
 {
@@ -12,6 +13,80 @@ SfmRoctx::SfmRoctx()
         pop = (int (*)())dlsym(h, "roctxRangePop");
         if (push && pop) return;
         push = nullptr; pop = nullptr;
+    }
+}
+
+int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return SFMHIP_OK;
+    if (bytes < ((size_t)4 << 20)) {
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SFMHIP_OK;
+    }
+    const size_t CH = sfmhip_ctx::STAGE_BYTES;
+    for (int b = 0; b < 2; ++b)
+        if (!ctx->stage[b]) {
+            SFM_HIP_TRY(ctx, hipHostMalloc(&ctx->stage[b], CH, hipHostMallocDefault));
+            SFM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
+        }
+    constexpr int NT = 4;
+    for (size_t off = 0; off < bytes; off += CH) {
+        const size_t n = std::min(CH, bytes - off);
+        const int b = ctx->stage_next;
+        if (ctx->stage_busy[b]) SFM_HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[b]));
+        const char* s = (const char*)src + off; char* d = (char*)ctx->stage[b];
+        std::thread helpers[NT - 1];
+        for (int t = 1; t < NT; ++t) helpers[t - 1] = std::thread([=] { const size_t a = n * t / NT, e = n * (t + 1) / NT; memcpy(d + a, s + a, e - a); });
+        memcpy(d, s, n / NT);
+        for (auto& th : helpers) th.join();
+        SFM_HIP_TRY(ctx, hipMemcpyAsync((char*)dst + off, d, n, hipMemcpyHostToDevice, ctx->stream));
+        SFM_HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[b], ctx->stream));
+        ctx->stage_busy[b] = true; ctx->stage_next = b ^ 1;
+    }
+    return SFMHIP_OK;
+}
+
+int sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes == 0) bytes = 256;
+    int best = -1;
+    const size_t hi = std::max(4 * bytes, (size_t)1 << 20);
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        const auto& b = ctx->pool[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= hi && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].used = true; ctx->pool_idle_bytes -= ctx->pool[best].bytes;
+        *out = ctx->pool[best].p;
+        return SFMHIP_OK;
+    }
+    void* q = nullptr;
+    SFM_HIP_TRY(ctx, hipMalloc(&q, bytes));
+    ctx->pool.push_back({ q, bytes, true });
+    *out = q;
+    return SFMHIP_OK;
+}
+
+void sfm_pool_put(sfmhip_ctx* ctx, void* p)
+{
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        auto& b = ctx->pool[i];
+        if (b.p != p) continue;
+        if (ctx->pool_idle_bytes + b.bytes > sfmhip_ctx::POOL_IDLE_CAP) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(b.p);
+            ctx->pool.erase(ctx->pool.begin() + i);
+        } else { b.used = false; ctx->pool_idle_bytes += b.bytes; }
+        return;
+    }
+}
+
+void sfm_pool_trim(sfmhip_ctx* ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t i = 0; i < ctx->pool.size();) {
+        if (!ctx->pool[i].used) { (void)hipFree(ctx->pool[i].p); ctx->pool_idle_bytes -= ctx->pool[i].bytes; ctx->pool.erase(ctx->pool.begin() + i); }
+        else ++i;
     }
 }
 
@@ -43,12 +118,23 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int b = 0; b < 2; ++b) { if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]); if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]); }
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     for (auto& t : ctx->tev) for (auto& e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+int sfmhip_trim(sfmhip_ctx* ctx)
+{
+    SFM_DEVICE_GUARD(ctx);
+    if (!ctx) return SFMHIP_E_ARG;
+    sfm_pool_trim(ctx);
+    return SFMHIP_OK;
 }
 
 int sfmhip_set_kernel_timing(sfmhip_ctx* ctx, int enable)
