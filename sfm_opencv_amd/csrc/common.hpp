@@ -29,6 +29,7 @@ struct sfmhip_ctx {
     hipEvent_t stage_ev[2] = { nullptr, nullptr };
     bool   stage_busy[2] = { false, false };
     int    stage_next = 0;
+    struct CopyPool* copy_pool = nullptr;      // three helper threads that fill the staging buffers beside the caller (context.hip)
     // Cache of device blocks (sfm_pool_get / sfm_pool_put): the arrays and the construction temporaries of bundle-adjustment
     // problems.  Giving gigabytes back to the driver costs ~0.1 s that surfaces in whatever HIP call comes next (measured: the
     // second sfmhip_ba_create at C5 took 127 ms against 13 ms for the first), so freed blocks are kept and handed out again;
@@ -37,6 +38,12 @@ struct sfmhip_ctx {
     std::vector<PoolBlock> pool;
     size_t pool_idle_bytes = 0;
     static constexpr size_t POOL_IDLE_CAP = (size_t)48 << 30;      // idle bytes kept at most (of 288 GB)
+    // "every value an integer in [0, 255]" flags of the descriptor sets, one slot each in ONE device array: the preparation
+    // kernels raise them, and a batch of sets is resolved with a single copy + sync when a launch first needs to know
+    static constexpr int FLAG_SLOTS = 1 << 16;
+    int*   d_flagpool = nullptr;
+    int    flag_next = 0;
+    std::vector<int> flag_free;
     // second stream of the bundle-adjustment problems (created on first use and kept: a hipStreamCreate costs milliseconds)
     hipStream_t aux_stream = nullptr;
     int    num_cus = 256;
@@ -140,8 +147,8 @@ static inline int sfm_pinned(sfmhip_ctx* ctx, size_t bytes, void** out)
 }
 
 // Host -> HBM copy of a caller's (pageable) array, ordered on the context's stream.  hipMemcpyAsync from pageable memory runs at
-// 9-13 GB/s on the MI355X boxes (one runtime thread staging); above 4 MB this goes through two pinned 16 MB buffers filled by four
-// host threads instead (43 GB/s, experiments/h2d_bench.hip).  The source may be reused as soon as the call returns.
+// 9-13 GB/s on the MI355X boxes (one runtime thread staging); this goes through two pinned 16 MB buffers filled by four host
+// threads instead (43 GB/s, experiments/h2d_bench.hip).  The source has been consumed when the call returns.
 int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 // device block of at least `bytes` from the context's cache (an idle block of up to 4x the size, else a new hipMalloc); stream-ordered
@@ -164,7 +171,9 @@ struct sfmhip_descset {
     int dim_pad = 0;                  // multiple of 32 (int8 copy row length in bytes)
     int8_t* d_i8 = nullptr;           // rows_pad x dim_pad, value - 128; pad rows zero
     int32_t* d_norm = nullptr;        // 2 x rows_pad: [sum b^2 | sum b^2 + 2 sum b], b = value - 128; pad rows = PAD_NORM
-    int exact_u8 = 0;                 // every value an integer in [0,255] and dim <= 128
+    int exact_u8 = 0;                 // every value an integer in [0,255] and dim <= 128 (valid once !exact_pending)
+    bool exact_pending = false;       // the preparation kernel's verdict is still in d_flag (descsets_resolve reads it)
+    int flag_slot = -1;               // d_flag = ctx->d_flagpool + flag_slot; -1: a block of its own
     // Hamming2
     uint32_t* d_u32 = nullptr;        // rows_pad x 16 words (64 B rows, zero padded)
     int* d_flag = nullptr;

@@ -2,6 +2,8 @@
 #include "common.hpp"
 #include <cfloat>
 #include <dlfcn.h>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 SfmRoctx::SfmRoctx()
@@ -16,29 +18,64 @@ SfmRoctx::SfmRoctx()
     }
 }
 
+// Helper threads of sfm_upload: they sleep on a condition variable and each copies one slice of the current piece.
+struct CopyPool {
+    static constexpr int NT = 4;               // the caller + three helpers
+    std::thread th[NT - 1];
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    unsigned long long gen = 0; int pending = 0; bool quit = false;
+    const char* src = nullptr; char* dst = nullptr; size_t n = 0;
+    static void slice(const char* s, char* d, size_t n, int t) { const size_t a = n * t / NT, e = n * (t + 1) / NT; memcpy(d + a, s + a, e - a); }
+    CopyPool()
+    {
+        for (int t = 1; t < NT; ++t)
+            th[t - 1] = std::thread([this, t] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_go.wait(lk, [&] { return quit || gen != seen; });
+                    if (quit) return;
+                    seen = gen;
+                    const char* s = src; char* d = dst; const size_t cnt = n;
+                    lk.unlock();
+                    slice(s, d, cnt, t);
+                    lk.lock();
+                    if (--pending == 0) cv_done.notify_one();
+                }
+            });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void copy(const char* s, char* d, size_t cnt)
+    {
+        { std::lock_guard<std::mutex> lk(mu); src = s; dst = d; n = cnt; pending = NT - 1; ++gen; }
+        cv_go.notify_all();
+        slice(s, d, cnt, 0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
 int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (bytes == 0) return SFMHIP_OK;
-    if (bytes < ((size_t)4 << 20)) {
-        SFM_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return SFMHIP_OK;
-    }
     const size_t CH = sfmhip_ctx::STAGE_BYTES;
     for (int b = 0; b < 2; ++b)
         if (!ctx->stage[b]) {
             SFM_HIP_TRY(ctx, hipHostMalloc(&ctx->stage[b], CH, hipHostMallocDefault));
             SFM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
         }
-    constexpr int NT = 4;
+    if (bytes >= ((size_t)1 << 20) && !ctx->copy_pool) ctx->copy_pool = new CopyPool();
     for (size_t off = 0; off < bytes; off += CH) {
         const size_t n = std::min(CH, bytes - off);
         const int b = ctx->stage_next;
         if (ctx->stage_busy[b]) SFM_HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[b]));
         const char* s = (const char*)src + off; char* d = (char*)ctx->stage[b];
-        std::thread helpers[NT - 1];
-        for (int t = 1; t < NT; ++t) helpers[t - 1] = std::thread([=] { const size_t a = n * t / NT, e = n * (t + 1) / NT; memcpy(d + a, s + a, e - a); });
-        memcpy(d, s, n / NT);
-        for (auto& th : helpers) th.join();
+        if (n >= ((size_t)1 << 20)) ctx->copy_pool->copy(s, d, n); else memcpy(d, s, n);
         SFM_HIP_TRY(ctx, hipMemcpyAsync((char*)dst + off, d, n, hipMemcpyHostToDevice, ctx->stream));
         SFM_HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[b], ctx->stream));
         ctx->stage_busy[b] = true; ctx->stage_next = b ^ 1;
@@ -119,9 +156,11 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
+    if (ctx->d_flagpool) (void)hipFree(ctx->d_flagpool);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx->copy_pool;
     for (int b = 0; b < 2; ++b) { if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]); if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]); }
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     for (auto& t : ctx->tev) for (auto& e : t) if (e) (void)hipEventDestroy(e);
@@ -171,7 +210,10 @@ int sfmhip_match_kernel_ms(sfmhip_ctx* ctx, double out_ms[4])
 int sfmhip_set_stream(sfmhip_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return SFMHIP_E_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    // cached device blocks and the staging ring are reused in stream order: drain the old stream before work moves to another
+    if (next != ctx->stream) { SFM_DEVICE_GUARD(ctx); (void)hipStreamSynchronize(ctx->stream); }
+    ctx->stream = next;
     return SFMHIP_OK;
 }
 

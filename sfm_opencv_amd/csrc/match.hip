@@ -799,23 +799,63 @@ static int descset_alloc_common(sfmhip_ctx* ctx, int kind, int rows, int dim, sf
     return SFMHIP_OK;
 }
 
+static int descset_flag_slot(sfmhip_ctx* ctx, sfmhip_descset* s)
+{
+    if (!ctx->d_flagpool) SFM_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_flagpool, sfmhip_ctx::FLAG_SLOTS * sizeof(int)));
+    if (!ctx->flag_free.empty()) { s->flag_slot = ctx->flag_free.back(); ctx->flag_free.pop_back(); }
+    else if (ctx->flag_next < sfmhip_ctx::FLAG_SLOTS) s->flag_slot = ctx->flag_next++;
+    if (s->flag_slot >= 0) { s->d_flag = ctx->d_flagpool + s->flag_slot; return SFMHIP_OK; }
+    void* q = nullptr;
+    int rc = sfm_pool_get(ctx, 256, &q); if (rc) return rc;
+    s->d_flag = (int*)q;
+    return SFMHIP_OK;
+}
+
+// The preparation kernels leave "not every value is an integer in [0, 255]" in the sets' flags; whoever needs the verdict
+// (path selection of a launch, sfmhip_descset_info) resolves all pending sets of its batch with one copy and one sync --
+// a chain of N images prepared from host rows costs one round trip, not N.
+static int descsets_resolve(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
+{
+    int lo = INT_MAX, hi = -1; bool any = false;
+    for (int i = 0; i < n; ++i) {
+        sfmhip_descset* s = sets[i];
+        if (!s || !s->exact_pending) continue;
+        any = true;
+        if (s->flag_slot >= 0) { lo = std::min(lo, s->flag_slot); hi = std::max(hi, s->flag_slot); }
+    }
+    if (!any) return SFMHIP_OK;
+    std::vector<int> host;
+    if (hi >= 0) {
+        host.resize((size_t)(hi - lo + 1));
+        SFM_HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_flagpool + lo, host.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) {
+        sfmhip_descset* s = sets[i];
+        if (!s || !s->exact_pending) continue;
+        int flag = 0;
+        if (s->flag_slot >= 0) flag = host[(size_t)(s->flag_slot - lo)];
+        else SFM_HIP_TRY(ctx, hipMemcpy(&flag, s->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+        s->exact_u8 = flag == 0; s->exact_pending = false;
+    }
+    return SFMHIP_OK;
+}
+
 static int descset_prepare_l2(sfmhip_ctx* ctx, sfmhip_descset* s)
 {
     s->dim_pad = s->dim <= 32 ? 32 : (s->dim <= 64 ? 64 : round_up(s->dim, 128));   // int8 row bytes: 32, 64 or 128
     const bool mfma_ok = s->dim_pad <= 128;    // d^2 <= 128*255^2 < 2^23 keeps the packed keys exact
     if (!mfma_ok) { s->exact_u8 = 0; return SFMHIP_OK; }
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_i8, (size_t)s->rows_pad * s->dim_pad));
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_norm, 2 * (size_t)s->rows_pad * sizeof(int32_t)));
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_flag, sizeof(int)));
+    void* q = nullptr;
+    int rc = sfm_pool_get(ctx, (size_t)s->rows_pad * s->dim_pad, &q); if (rc) return rc; s->d_i8 = (int8_t*)q;
+    rc = sfm_pool_get(ctx, 2 * (size_t)s->rows_pad * sizeof(int32_t), &q); if (rc) return rc; s->d_norm = (int32_t*)q;
+    rc = descset_flag_slot(ctx, s); if (rc) return rc;
     SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
     const int waves_per_block = 4;
     hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block * (256 / s->dim_pad))), dim3(64 * waves_per_block), 0, ctx->stream,
                        s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
     SFM_HIP_TRY(ctx, hipGetLastError());
-    int flag = 0;
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(&flag, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    s->exact_u8 = flag == 0;
+    s->exact_pending = true;
     return SFMHIP_OK;
 }
 
@@ -842,11 +882,15 @@ int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, 
     SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && dim > 0 && ld >= (size_t)dim);
     float* d = nullptr;
     const size_t nrow = rows > 0 ? rows : 1;
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&d, nrow * dim * sizeof(float)));
-    if (rows > 0) {
+    { void* q = nullptr; int rc = sfm_pool_get(ctx, nrow * dim * sizeof(float), &q); if (rc) return rc; d = (float*)q; }
+    if (rows > 0 && ld == (size_t)dim) {          // a dense cv::Mat (the reference's descriptors): through the pinned staging ring
+        const int rc = sfm_upload(ctx, d, desc, (size_t)rows * dim * sizeof(float));
+        if (rc) { sfm_pool_put(ctx, d); return rc; }
+    } else if (rows > 0) {
         hipError_t e = hipMemcpy2DAsync(d, dim * sizeof(float), desc, ld * sizeof(float), dim * sizeof(float), rows,
                                         hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the caller's rows must have been read when this returns
+        if (e != hipSuccess) { sfm_pool_put(ctx, d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
     }
     sfmhip_descset* s = nullptr;
     descset_alloc_common(ctx, SFMHIP_DESC_L2_F32, rows, dim, &s);
@@ -859,7 +903,7 @@ int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, 
 
 static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uint8_t* d_src, size_t ld)
 {
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&s->d_u32, (size_t)s->rows_pad * 64));
+    { void* q = nullptr; int rc = sfm_pool_get(ctx, (size_t)s->rows_pad * 64, &q); if (rc) return rc; s->d_u32 = (uint32_t*)q; }
     const size_t n = (size_t)s->rows_pad * 64;
     hipLaunchKernelGGL(prep_hamming_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_src, ld, s->rows, s->dim, (uint32_t*)s->d_u32, s->rows_pad);
@@ -887,16 +931,19 @@ int sfmhip_descset_create_hamming2_host(sfmhip_ctx* ctx, const uint8_t* desc, in
     SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && nbytes > 0 && nbytes <= 64 && ld >= (size_t)nbytes);
     uint8_t* d = nullptr;
     const size_t nrow = rows > 0 ? rows : 1;
-    SFM_HIP_TRY(ctx, hipMalloc((void**)&d, nrow * nbytes));
-    if (rows > 0) {
+    { void* q = nullptr; int rc = sfm_pool_get(ctx, nrow * nbytes, &q); if (rc) return rc; d = (uint8_t*)q; }
+    if (rows > 0 && ld == (size_t)nbytes) {
+        const int rc = sfm_upload(ctx, d, desc, (size_t)rows * nbytes);
+        if (rc) { sfm_pool_put(ctx, d); return rc; }
+    } else if (rows > 0) {
         hipError_t e = hipMemcpy2DAsync(d, nbytes, desc, ld, nbytes, rows, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { sfm_pool_put(ctx, d); ctx->last_error = hipGetErrorString(e); return SFMHIP_E_HIP; }
     }
     sfmhip_descset* s = nullptr;
     descset_alloc_common(ctx, SFMHIP_DESC_HAMMING2_U8, rows, nbytes, &s);
     int rc = descset_prepare_hamming(ctx, s, d, nbytes);
-    if (rc == SFMHIP_OK) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = SFMHIP_E_HIP; }
-    (void)hipFree(d);
+    sfm_pool_put(ctx, d);          // the byte rows are only read by the re-encoding kernel just enqueued (stream-ordered reuse)
     if (rc != SFMHIP_OK) { sfmhip_descset_destroy(s); return rc; }
     *out = s;
     return SFMHIP_OK;
@@ -906,12 +953,14 @@ void sfmhip_descset_destroy(sfmhip_descset* s)
 {
     SFM_DEVICE_GUARD(s ? s->ctx : nullptr);
     if (!s) return;
-    if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
-    if (s->owns_f32 && s->d_f32) (void)hipFree((void*)s->d_f32);
-    if (s->d_i8) (void)hipFree(s->d_i8);
-    if (s->d_norm) (void)hipFree(s->d_norm);
-    if (s->d_u32) (void)hipFree(s->d_u32);
-    if (s->d_flag) (void)hipFree(s->d_flag);
+    // the blocks go back to the context's cache; whoever gets them next works on the same stream, behind this set's last launch
+    sfmhip_ctx* ctx = s->ctx;
+    if (s->owns_f32 && s->d_f32) sfm_pool_put(ctx, (void*)s->d_f32);
+    if (s->d_i8) sfm_pool_put(ctx, s->d_i8);
+    if (s->d_norm) sfm_pool_put(ctx, s->d_norm);
+    if (s->d_u32) sfm_pool_put(ctx, s->d_u32);
+    if (s->flag_slot >= 0) ctx->flag_free.push_back(s->flag_slot);
+    else if (s->d_flag) sfm_pool_put(ctx, s->d_flag);
     delete s;
 }
 
@@ -962,7 +1011,7 @@ int sfmhip_descset_info(sfmhip_descset* s, int* kind, int* rows, int* dim, int* 
     if (kind) *kind = s->kind;
     if (rows) *rows = s->rows;
     if (dim) *dim = s->dim;
-    if (exact_u8) *exact_u8 = s->exact_u8;
+    if (exact_u8) { sfmhip_descset* one[1] = { s }; int rc = descsets_resolve(s->ctx, one, 1); if (rc) return rc; *exact_u8 = s->exact_u8; }
     return SFMHIP_OK;
 }
 
@@ -984,6 +1033,7 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
                       int force_path, KnnPlan& P)
 {
     SFM_ARG_CHECK(ctx, sets && pairs && n_pairs > 0 && n_sets > 0);
+    { int rc = descsets_resolve(ctx, sets, n_sets); if (rc) return rc; }
     bool all_exact = true; int kind = 0, dim = 0;
     for (int p = 0; p < n_pairs; ++p) {
         const int a = pairs[2 * p], b = pairs[2 * p + 1];
@@ -1280,6 +1330,7 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
     SFM_ARG_CHECK(ctx, query->kind == SFMHIP_DESC_L2_F32 && train->kind == SFMHIP_DESC_L2_F32 && query->dim == train->dim);
     SFM_ARG_CHECK(ctx, ld >= (size_t)train->rows);
     if (query->rows == 0 || train->rows == 0) return SFMHIP_OK;
+    { sfmhip_descset* two[2] = { const_cast<sfmhip_descset*>(query), const_cast<sfmhip_descset*>(train) }; int rc = descsets_resolve(ctx, two, 2); if (rc) return rc; }
     const bool exact = query->exact_u8 && train->exact_u8;
     SFM_ARG_CHECK(ctx, !(force_path == 2 && !exact));
     if (exact && force_path != 1) {

@@ -25,12 +25,15 @@ struct Huff {
     int mincode[17], maxcode[18], valptr[17];
     uint16_t look[512];                 // 9-bit prefix -> (length << 8) | symbol, 0 = longer code
     bool present = false;
-    void build()
+    // false: the code lengths over-subscribe the code space (libjpeg's check in jdhuff.c: at every length the running code must
+    // stay below 2^length) -- such a table would index past look[] below and past vals[] while decoding
+    bool build()
     {
         int code = 0, k = 0;
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k; mincode[l] = code;
             code += bits[l]; k += bits[l];
+            if (code > (1 << l) || k > 256) return false;
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -40,10 +43,11 @@ struct Huff {
         for (int l = 1; l <= 9; ++l) {
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
                 const int lo = code << (9 - l);
-                for (int f = 0; f < (1 << (9 - l)); ++f) look[lo + f] = (uint16_t)((l << 8) | vals[k]);
+                for (int f = 0; f < (1 << (9 - l)) && lo + f < 512; ++f) look[lo + f] = (uint16_t)((l << 8) | vals[k]);
             }
             code <<= 1;
         }
+        return true;
     }
 };
 
@@ -229,7 +233,8 @@ inline bool decode_jpeg(const uint8_t* d, size_t n, int& rows, int& cols, int& c
                 for (int l = 1; l <= 16; ++l) { h.bits[l] = s[k++]; total += h.bits[l]; }
                 if (total > 256 || k + total > sl) return false;
                 memcpy(h.vals, s + k, (size_t)total); k += total;
-                h.build(); h.present = true;
+                if (!h.build()) return false;
+                h.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) {            // SOF0 / SOF1
             if (sl < 6 || s[0] != 8) return false;
@@ -296,15 +301,16 @@ inline bool decode_jpeg(const uint8_t* d, size_t n, int& rows, int& cols, int& c
                         memset(coef, 0, sizeof coef);
                         const uint16_t* q = qt[c.tq];
                         int s = decode_symbol(br, hdc[c.td]);
-                        if (s > 15) return false;
+                        if (s > 11) return false;                 // DC difference category of 8-bit data: 0..11 (ITU T.81 F.1.2.1)
                         c.pred += extend(br.get(s), s);
+                        if (c.pred < -32768 || c.pred > 32767) return false;      // outside what any encoder of 8-bit samples emits
                         coef[0] = c.pred * q[0];
                         for (int k = 1; k < 64;) {
                             const int rs = decode_symbol(br, hac[c.ta]);
                             const int r = rs >> 4; s = rs & 15;
                             if (s == 0) { if (r == 15) { k += 16; continue; } break; }
                             k += r;
-                            if (k > 63) return false;
+                            if (k > 63 || s > 10) return false;       // AC category of 8-bit data: 1..10
                             const int z = kZigzag[k];
                             coef[z] = extend(br.get(s), s) * q[z];
                             ++k;
