@@ -187,8 +187,15 @@ def main():
     sc = synth.ba_scene(n_img, n_pt)
     pts_l, oc_l, op_l, uv_l, _ = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], rank, world)
     pb = ctx.ba_create(sc["K0"], sc["ext0"], pts_l, oc_l, op_l, uv_l)
+    native_comm = None
     if world > 1:
-        pb.set_allreduce(sdist.make_allreduce_hook(), rank, world)
+        # production: the in-library RCCL hook (ncclAllReduce on the context's stream, no Python between the LM loop and the
+        # collective).  gloo rehearsals (several ranks on one card, SFM_DIST_BACKEND=gloo) go through torch.distributed instead.
+        if dist.get_backend() == "nccl" and ctx.rccl_available() and os.environ.get("SFM_NATIVE_RCCL", "1") != "0":
+            native_comm = sdist.make_native_rccl(ctx)
+            pb.set_rccl(native_comm, rank, world)
+        else:
+            pb.set_allreduce(sdist.make_allreduce_hook(), rank, world)
     s0 = pb.iterate(args.warmup) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
@@ -490,7 +497,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img_match - 1} chain pairs matched), "
                                    f"{n_img} cameras / {n_pt} points / {n_obs} observations BA",
-                       "parallelism": f"points+pairs sharded over {world} rank(s), cameras replicated, 2 all-reduces/iteration (packed reduced-system message + 5 step scalars)",
+                       "parallelism": f"points (by first camera) + pairs sharded over {world} rank(s), cameras replicated, 1 all-reduce per LM iteration (packed reduced-system "
+                                      f"message of the speculative next linearisation + the 5 step scalars; {'in-library RCCL hook' if native_comm is not None else ('torch.distributed hook' if world > 1 else 'no exchange')})",
                        "reduced_system_order": n_red},
             "roofline": roof,
             "roofline_lm_iteration": {"bound": "hbm", "achieved": b_it / (phase[3] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

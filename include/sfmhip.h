@@ -239,8 +239,21 @@ void sfmhip_ba_destroy(sfmhip_ba*);
  * ranks, ordered on `hip_stream`; return 0 on success.  (RCCL: ncclAllReduce(d_buf,d_buf,count,
  * ncclDouble,ncclSum,comm,stream); torch.distributed: dist.all_reduce on a tensor view.) */
 typedef int (*sfmhip_allreduce_fn)(void* user, void* d_buf, size_t count, void* hip_stream);
-/* rank / world: this process's index and the number of ranks (<= 64); resets the LM state. */
+/* rank / world: this process's index and the number of ranks (<= 64); resets the LM state.
+ * On several ranks an LM iteration costs ONE call of the hook: the step's scalars (model cost change, candidate cost, step and
+ * parameter norms, error flag) ride in the message of the next linearisation, which is built speculatively at the candidate
+ * point; a rejected step (or a trust-region radius other than the guessed one) discards it and costs one more call. */
 int  sfmhip_ba_set_allreduce(sfmhip_ba*, sfmhip_allreduce_fn fn, void* user, int rank, int world);
+/* The production hook, inside the library: RCCL over xGMI, librccl.so looked up at run time (SFMHIP_E_COMM without it).
+ * Rank 0 obtains the 128-byte unique id, the launcher hands it to every rank (torch.distributed / MPI / a file), every rank creates
+ * its communicator on the context's device and installs it: the LM loop then calls ncclAllReduce(double, sum, in place) on the
+ * context's stream itself.  No reference counterpart (the reference is one CPU process, NView:1334-1524). */
+int  sfmhip_rccl_available(void);
+int  sfmhip_rccl_get_unique_id(void* id128);
+int  sfmhip_rccl_comm_create(sfmhip_ctx*, const void* id128, int rank, int world, void** comm);
+int  sfmhip_rccl_comm_destroy(void* comm);
+int  sfmhip_ba_set_rccl(sfmhip_ba*, void* comm, int rank, int world);
+int  sfmhip_rccl_allreduce_f64(sfmhip_ctx*, void* comm, void* d_buf, size_t count);
 /* run the LM loop to termination */
 int  sfmhip_ba_run(sfmhip_ba*, sfm_ba_summary* summary);
 /* run exactly n_iter LM iterations (tolerance checks disabled); state carries over between calls */

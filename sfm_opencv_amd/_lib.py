@@ -56,6 +56,8 @@ SYMBOLS = [
     "sfmhip_ba_set_allreduce", "sfmhip_ba_run", "sfmhip_ba_iterate", "sfmhip_ba_reset",
     "sfmhip_ba_get_params", "sfmhip_ba_reduced_system", "sfmhip_ba_phase_ms", "sfmhip_ba_debug_table",
     "sfmhip_estimate_normals",
+    "sfmhip_rccl_available", "sfmhip_rccl_get_unique_id", "sfmhip_rccl_comm_create", "sfmhip_rccl_comm_destroy",
+    "sfmhip_ba_set_rccl", "sfmhip_rccl_allreduce_f64",
 ]
 
 _lib = None
@@ -123,6 +125,12 @@ def load():
         "sfmhip_ba_phase_ms": (i32, [vp, C.POINTER(f64)]),
         "sfmhip_ba_debug_table": (i32, [vp, C.c_char_p, vp, sz, C.POINTER(sz)]),
         "sfmhip_estimate_normals": (i32, [vp, vp, i32, i32, vp]),
+        "sfmhip_rccl_available": (i32, []),
+        "sfmhip_rccl_get_unique_id": (i32, [vp]),
+        "sfmhip_rccl_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "sfmhip_rccl_comm_destroy": (i32, [vp]),
+        "sfmhip_ba_set_rccl": (i32, [vp, vp, i32, i32]),
+        "sfmhip_rccl_allreduce_f64": (i32, [vp, vp, vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -84,6 +84,28 @@ class Context:
     def synchronize(self):
         self._check(self.lib.sfmhip_synchronize(self.h))
 
+    # ---------------------------------------------------------------- RCCL (multi-GPU)
+    def rccl_available(self):
+        return bool(self.lib.sfmhip_rccl_available())
+
+    def rccl_unique_id(self):
+        """128 opaque bytes from ncclGetUniqueId (rank 0; ship them to the other ranks)"""
+        buf = (C.c_char * 128)()
+        self._check(self.lib.sfmhip_rccl_get_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_comm_create(self, unique_id, rank, world):
+        comm = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.sfmhip_rccl_comm_create(self.h, buf, int(rank), int(world), C.byref(comm)))
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        self._check(self.lib.sfmhip_rccl_comm_destroy(comm))
+
+    def rccl_allreduce_f64(self, comm, dev_ptr, count):
+        self._check(self.lib.sfmhip_rccl_allreduce_f64(self.h, comm, C.c_void_p(int(dev_ptr)), int(count)))
+
     def trim(self):
         """release the device blocks the context keeps from destroyed BA problems (sfmhip_trim)"""
         self._check(self.lib.sfmhip_trim(self.h))
@@ -279,6 +301,11 @@ class BAProblem:
                 return -1
         self._cb = _lib.ALLREDUCE_FN(_tramp)
         self.ctx._check(self.ctx.lib.sfmhip_ba_set_allreduce(self.h, self._cb, None, int(rank), int(world)))
+
+    def set_rccl(self, comm, rank, world):
+        """install the in-library RCCL hook (sfmhip_ba_set_rccl); comm from Context.rccl_comm_create"""
+        self._cb = None
+        self.ctx._check(self.ctx.lib.sfmhip_ba_set_rccl(self.h, comm, int(rank), int(world)))
 
     def run(self):
         s = BASummary()

@@ -133,8 +133,12 @@ __global__ __launch_bounds__(1024) void chol_solve_kernel(const double* __restri
 // Multi-rank message: only the 32x32 blocks of the lower triangle that the Schur complement can populate (camera
 // adjacency + intrinsics row, diagonal blocks whole) plus the tail [rhs | diagU | graw | scalars] travel through the
 // all-reduce hook -- at C4 1.4 MB instead of the 12 MB dense square.  dir 0: S -> message, 1: message -> S.
+// carry (multi-rank, folded step scalars): the five scalars of the step just taken [model cost change, candidate cost, |dp|^2,
+// |x_p|^2, error flag] ride in the free slots scal[2..6] of the message of the NEXT linearisation ("fuse the
+// candidate-cost scalar into the next iteration's message"); unpacking hands their sums back.  carry_off = offset of scal[2] in the tail.
 __global__ __launch_bounds__(256) void ba_pack_kernel(double* __restrict__ S, int ld, const int* __restrict__ sblk, int n_sblk,
-                                                      double* __restrict__ tail, size_t tail_count, double* __restrict__ msg, int dir)
+                                                      double* __restrict__ tail, size_t tail_count, double* __restrict__ msg, int dir,
+                                                      double* __restrict__ carry, size_t carry_off)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b < n_sblk) {
@@ -147,7 +151,9 @@ __global__ __launch_bounds__(256) void ba_pack_kernel(double* __restrict__ S, in
     } else {
         const size_t base = (size_t)n_sblk * NB * NB;
         for (size_t e = (size_t)(b - n_sblk) * 256 + tid; e < tail_count; e += (size_t)(gridDim.x - n_sblk) * 256) {
-            if (dir == 0) msg[base + e] = tail[e]; else tail[e] = msg[base + e];
+            if (carry && e >= carry_off && e < carry_off + 5) {
+                if (dir == 0) msg[base + e] = carry[e - carry_off]; else carry[e - carry_off] = msg[base + e];
+            } else if (dir == 0) msg[base + e] = tail[e]; else tail[e] = msg[base + e];
         }
     }
 }
@@ -209,7 +215,10 @@ struct sfmhip_ba {
     hipEvent_t evb[2][5] = {};          // per build parity: [start, camera kernel begin/end, pair kernel begin/end]
     hipEvent_t evi[2][5] = {};          // per iteration parity: [damped, solved, back-substituted, forward kernel begin/end]
     int iter_parity = 0, pending_build = -1, pending_iter = -1;       // timings not yet read (read off the decision path)
-    bool cleared = false;               // d_msg / d_err are already zeroed for the next build (done behind the scalar copies)
+    bool cleared = false;               // S (the npad x npad part of d_msg) is already zero for the next build -- ONLY S: the tail [rhs | diagU | graw | scalars]
+                                        // and d_err are not refilled, they rely on the finalisation storing every real entry (padding entries stay zero
+                                        // through the solve) and on ba_back_reduce_kernel re-arming the error flag; tests/test_ba_gpu.py::
+                                        // test_reused_message_tail_with_an_unobserved_camera holds both linearisers to that
     bool top_cleared = false;      // d_topbuf was zero-filled ahead of time (behind the publish kernel, while the host decides)
     int n_diag_blk = 0;            // camera pairs (a, a): a point seen twice by one camera
     bool solver_damps = false; double damp_radius = 0.0;    // the next enqueue_solve applies the LM damping inside its kernels
@@ -218,6 +227,8 @@ struct sfmhip_ba {
     bool publish_in_back = false, published = false;   // ba_loop asks enqueue_back to publish the step scalars from its reduction kernel
     bool campre_valid = false;     // d_campre matches d_ext (kept across iterations: an accepted step swaps in the candidate's)
     unsigned long long pub_seq = 0; // sequence number of the last ba_publish_kernel
+    bool fold_step_scalars = false; // set by ba_loop on several ranks: enqueue_back leaves the step scalars to the next message
+    long long ar_calls = 0;         // all-reduce hook invocations since sfmhip_ba_set_allreduce (tests assert one per LM iteration)
     bool force_dense = false;      // SFMHIP_EXPERIMENTS builds: SFMHIP_DENSE_SOLVER routes every problem to the dense fallback
     long long* d_stamps = nullptr; int stamp_calls = 0;      // SFMHIP_EXPERIMENTS builds only: per-panel cycle stamps of the solver
     // run-tile linearisation (ba_tiles.hpp): segments of point runs, their tiles, and the fold table of ba_tile_reduce_kernel
@@ -298,16 +309,17 @@ static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = fal
 static int call_allreduce(sfmhip_ba* h, double* buf, size_t count)
 {
     if (!h->ar_fn) return SFMHIP_OK;
+    ++h->ar_calls;
     const int rc = h->ar_fn(h->ar_user, buf, count, (void*)h->ctx->stream);
     if (rc != 0) { h->ctx->last_error = "all-reduce hook failed"; return SFMHIP_E_COMM; }
     return SFMHIP_OK;
 }
 
-static int enqueue_build_exchange(sfmhip_ba* h);
+static int enqueue_build_exchange(sfmhip_ba* h, double* carry);
 
 // linearise: message = [S | rhs | diagU | graw | scal] (undamped), summed over ranks.  at_candidate: at the candidate
 // parameters the last back-substitution produced (speculative build of the next iteration, see ba_loop).
-static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool timed)
+static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool timed, double* carry = nullptr)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
@@ -333,7 +345,7 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
         hipLaunchKernelGGL(ba_tile_reduce_kernel, dim3(h->rd_n_long + ceil_div(h->rd_nd - h->rd_n_long, 256) + 1), dim3(256), 0, st, P, h->d_rd_start, h->d_rd_dst, h->d_rd_dst2, h->d_rd_src,
                            h->rd_n_long, h->rd_nd, h->d_tpart, h->d_tpart_seg, h->n_tseg);
         SFM_HIP_TRY(ctx, hipGetLastError());
-        return enqueue_build_exchange(h);
+        return enqueue_build_exchange(h, carry);
     }
     hipLaunchKernelGGL(ba_point_kernel, dim3(h->n_pt_blocks), dim3(256), 0, st, P, h->d_err);
     // camera items and pair chunks in one launch, then their folds in one launch (ba_kernels.hpp: ba_camschur_kernel)
@@ -368,23 +380,24 @@ static int enqueue_build(sfmhip_ba* h, double radius, bool at_candidate, bool ti
     if (h->n_diag_blk > 0)
         hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(ceil_div(h->nblk * 36, 256)), dim3(256), 0, st, P, h->d_blk_cam, h->d_blk_chunk, h->nblk, h->d_part_schur, 1);
     SFM_HIP_TRY(ctx, hipGetLastError());
-    return enqueue_build_exchange(h);
+    return enqueue_build_exchange(h, carry);
 }
 
 // multi-rank: the packed sum of the reduced-system message over the ranks
-static int enqueue_build_exchange(sfmhip_ba* h)
+static int enqueue_build_exchange(sfmhip_ba* h, double* carry)
 {
     sfmhip_ctx* ctx = h->ctx;
     hipStream_t st = ctx->stream;
     if (h->ar_fn) {
         const size_t np2 = (size_t)h->npad * h->npad, tail = h->msg_count - np2, count = (size_t)h->n_sblk * NB * NB + tail;
         const int tail_blocks = (int)std::min<size_t>((tail + 255) / 256, 64);
+        const size_t carry_off = 3 * (size_t)h->npad + 2;          // scal[2] inside the tail [rhs | diagU | graw | scal]
         hipLaunchKernelGGL(ba_pack_kernel, dim3(h->n_sblk + tail_blocks), dim3(256), 0, st, h->d_msg, h->npad, h->d_sblk, h->n_sblk,
-                           h->d_msg + np2, tail, h->d_pack, 0);
+                           h->d_msg + np2, tail, h->d_pack, 0, carry, carry_off);
         SFM_HIP_TRY(ctx, hipGetLastError());
         int rc = call_allreduce(h, h->d_pack, count); if (rc) return rc;
         hipLaunchKernelGGL(ba_pack_kernel, dim3(h->n_sblk + tail_blocks), dim3(256), 0, st, h->d_msg, h->npad, h->d_sblk, h->n_sblk,
-                           h->d_msg + np2, tail, h->d_pack, 1);
+                           h->d_msg + np2, tail, h->d_pack, 1, carry, carry_off);
         SFM_HIP_TRY(ctx, hipGetLastError());
     }
     return SFMHIP_OK;
@@ -503,7 +516,9 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     h->published = fuse_publish;
     SFM_HIP_TRY(ctx, hipGetLastError());
     // five doubles: the four step scalars and this rank's error flag (a non-SPD V of a local point): every rank must take
-    // the same accept / invalid branch, or the replicated cameras, radius and nu diverge and the next all-reduce hangs
+    // the same accept / invalid branch, or the replicated cameras, radius and nu diverge and the next all-reduce hangs.
+    // Folded (ba_loop on several ranks): they travel with the message of the speculative linearisation that follows instead.
+    if (h->fold_step_scalars) return SFMHIP_OK;
     return call_allreduce(h, h->d_back4, 5);
 }
 
@@ -972,11 +987,16 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
     // good step), so that an accepted step finds its build already running.  Measured at C4: 11 of 12 guesses hit, results
     // bit-identical, but no gain (0.695 vs 0.686 ms per step): the round trip is ~10 us of a 0.67 ms iteration and the extra
     // enqueue work costs as much.  Off by default.
+    // On several ranks the speculation is how the LM iteration gets by with ONE collective: the step's five scalars ride in the
+    // message of the speculative linearisation at the candidate (accepted with the guessed radius: the next iteration starts
+    // from it; rejected or another radius: it is discarded and the next iteration linearises again -- one more collective).
 #ifdef SFMHIP_EXPERIMENTS
-    static const bool speculate = getenv("SFMHIP_SPECULATE") != nullptr;
+    static const bool speculate_env = getenv("SFMHIP_SPECULATE") != nullptr;
 #else
-    constexpr bool speculate = false;
+    constexpr bool speculate_env = false;
 #endif
+    const bool folded = h->ar_fn != nullptr;
+    const bool speculate = speculate_env || folded;
     for (;;) {
         if (h->iter >= it_end) { h->termination = SFMHIP_BA_NO_CONVERGENCE; break; }
         if (!forced && h->radius < o.min_trust_region_radius) { h->termination = SFMHIP_BA_CONVERGENCE; break; }
@@ -992,21 +1012,25 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
         rc = enqueue_solve(h); if (rc) return rc;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[1], st));
-        h->publish_in_back = true;
-        rc = enqueue_back(h, h->radius); h->publish_in_back = false; if (rc) return rc;
+        h->publish_in_back = true; h->fold_step_scalars = folded;
+        rc = enqueue_back(h, h->radius); h->publish_in_back = false; h->fold_step_scalars = false; if (rc) return rc;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[2], st));
+        // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
+        // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
+        bool speculated = false;
+        const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
+        // folded: ba_back_reduce_kernel has parked this linearisation's cost and gradient maximum in d_back4[5..6] (the build below
+        // overwrites the message tail they live in), and the exchange of the build sums d_back4[0..4] over the ranks
+        if (folded) { rc = enqueue_build(h, spec_radius, true, true, h->d_back4); if (rc) return rc; speculated = true; }
         // one wave gathers the nine scalars into pinned host memory and bumps a sequence number the host polls; it also
         // re-arms the error flag.  The next build's zero-fill does not depend on the decision: it runs while the host decides.
         unsigned long long seq = h->pub_seq;
         if (!h->published) {
             seq = ++h->pub_seq;
-            hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq, h->ar_fn ? 0 : 1);
+            hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, st, folded ? (const double*)(h->d_back4 + 5) : d_scal, h->d_back4, h->d_cam2, h->d_err, h->h_scal, seq,
+                               folded ? 2 : (h->ar_fn ? 0 : 1));
         }
-        // the point blocks are damped inside the build, so the speculation must also guess the next radius: a step with
-        // rho >= 0.937 (the normal case while LM is making progress) grows it by exactly 1 / (1/3)
-        bool speculated = false;
-        const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
-        if (speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
+        if (!folded && speculate && h->iter + 1 < it_end) { rc = enqueue_build(h, spec_radius, true, true); if (rc) return rc; speculated = true; }
         read_pending_timing(h);                     // the PREVIOUS iteration's events, while the GPU works on this one
         if (timing) { h->pending_build = par; h->pending_iter = h->iter_parity; }
         {   // spin on the sequence number; if the stream drains without publishing (a failed launch) the query ends the wait.

@@ -937,9 +937,10 @@ __global__ void ba_publish_kernel(const double* __restrict__ scal2, const double
     else if (l < 6) host_out[l] = back4[l - 2];
     else if (l < 8) host_out[l] = cam2[l - 6];
     else if (l == 8) {
-        // clear_err == 0 <=> multi-rank: back4[4] is the all-reduced flag count, the local flag is re-armed by the next build
-        host_out[8] = clear_err ? (double)*err : ((*err != 0 || back4[4] > 0.0) ? 1.0 : 0.0);
-        if (clear_err) *err = 0;
+        // clear_err == 0 <=> multi-rank: back4[4] is the all-reduced flag count, the local flag is re-armed by the next build;
+        // 2 <=> multi-rank with folded step scalars: *err already belongs to the speculative linearisation, only back4[4] counts
+        host_out[8] = clear_err == 1 ? (double)*err : (((clear_err == 0 && *err != 0) || back4[4] > 0.0) ? 1.0 : 0.0);
+        if (clear_err == 1) *err = 0;
     }
     __threadfence_system();
     __syncthreads();
@@ -1112,8 +1113,11 @@ __global__ __launch_bounds__(256) void ba_back_reduce_kernel(const double* __res
         out4[threadIdx.x] = v;
         if (host_out) host_out[2 + threadIdx.x] = v;
     }
-    // multi-rank: the error flag travels with the step scalars (summed by the all-reduce: > 0 on every rank if any rank set it)
+    // multi-rank: the error flag travels with the step scalars (summed by the all-reduce: > 0 on every rank if any rank set it);
+    // out4[5..6] keep this linearisation's cost and gradient maximum (scal2[0..1]) for the publish kernel: with the step scalars
+    // folded into the next message, the next build has overwritten the message tail by the time the host is told
     if (!host_out && threadIdx.x == 4) out4[4] = *err != 0 ? 1.0 : 0.0;
+    if (!host_out && (threadIdx.x == 5 || threadIdx.x == 6)) out4[threadIdx.x] = scal2[threadIdx.x - 5];
     if (host_out) {
         const int l = threadIdx.x;
         if (l >= 64 && l < 66) host_out[l - 64] = scal2[l - 64];

@@ -52,20 +52,32 @@ def shard_pairs(n_img, rank, world):
     return pairs_global, images, pairs_local
 
 
-def shard_points(obs_cam, obs_pt, obs_uv, pts, rank, world):
-    """Partition points into contiguous id ranges with (nearly) equal observation counts; returns this rank's
-    (pts_local, obs_cam_local, obs_pt_local (re-indexed), obs_uv_local, point_ids)."""
-    obs_pt = np.asarray(obs_pt); n_pt = len(pts)
+def shard_points(obs_cam, obs_pt, obs_uv, pts, rank, world, by="first_camera"):
+    """Partition the points (with all their observations) over the ranks, (nearly) equal observation counts per rank.
+    by="first_camera" (default): points ordered by the lowest camera that sees them and cut into contiguous runs -- "by the image
+    pair that created the point" (NViewReconstuct.cpp:1297-1299 appends a point when its first pair is fused), so a
+    rank works on a window of the camera chain: its partial reduced system touches only that window's band, and its kernels
+    gather from a fraction of the camera blocks.  by="id": contiguous point-id ranges (round 1-2 behaviour).
+    Returns this rank's (pts_local, obs_cam_local, obs_pt_local (re-indexed), obs_uv_local, point_ids)."""
+    obs_pt = np.asarray(obs_pt); obs_cam = np.asarray(obs_cam); n_pt = len(pts)
     cnt = np.bincount(obs_pt, minlength=n_pt)
-    cum = np.concatenate([[0], np.cumsum(cnt)])
+    if by == "first_camera":
+        first = np.full(n_pt, np.iinfo(np.int64).max, np.int64)
+        np.minimum.at(first, obs_pt, obs_cam.astype(np.int64))
+        order = np.argsort(first, kind="stable")            # points without observations go last
+    elif by == "id":
+        order = np.arange(n_pt)
+    else:
+        raise ValueError(by)
+    cum = np.concatenate([[0], np.cumsum(cnt[order])])
     total = cum[-1]
     bounds = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world)] + [n_pt]
     bounds[0] = 0
-    lo, hi = bounds[rank], bounds[rank + 1]
-    sel = (obs_pt >= lo) & (obs_pt < hi)
-    ids = np.arange(lo, hi)
-    return (np.ascontiguousarray(pts[lo:hi]), np.ascontiguousarray(np.asarray(obs_cam)[sel]),
-            np.ascontiguousarray(obs_pt[sel] - lo).astype(np.int32), np.ascontiguousarray(np.asarray(obs_uv)[sel]), ids)
+    ids = np.sort(order[bounds[rank]:bounds[rank + 1]])     # ascending ids: the local order is the caller's order restricted to the shard
+    local = np.full(n_pt, -1, np.int64); local[ids] = np.arange(len(ids))
+    sel = local[obs_pt] >= 0
+    return (np.ascontiguousarray(np.asarray(pts)[ids]), np.ascontiguousarray(obs_cam[sel]),
+            np.ascontiguousarray(local[obs_pt[sel]]).astype(np.int32), np.ascontiguousarray(np.asarray(obs_uv)[sel]), ids)
 
 
 class _CudaView:
@@ -102,3 +114,20 @@ def make_allreduce_hook(group=None, device="cuda"):
         return 0
 
     return hook
+
+
+def make_native_rccl(ctx, group=None):
+    """Communicator for the in-library RCCL hook (sfmhip_ba_set_rccl): rank 0 draws the unique id, torch.distributed carries its 128
+    bytes to the other ranks, every rank creates its communicator on the context's device.  Returns the opaque communicator
+    (BAProblem.set_rccl(comm, rank, world)); the LM loop then calls ncclAllReduce itself, no Python in between."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    uid = ctx.rccl_unique_id() if rank == 0 else bytes(128)
+    if world > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        uid = bytes(t.cpu().tolist())
+    return ctx.rccl_comm_create(uid, rank, world)

@@ -226,7 +226,8 @@ struct PipelineOptions {
     int max_features = 0;                  // directory input: keep the strongest N key points per image (0: all, like the reference)
     std::string save_features;             // directory input: also write the extracted features to this file
     bool features_only = false;            // ... and stop there
-    bool akaze = false;                    // directory input: AKAZE + M-LDB rows (the reference's live extractor, NView:797) instead of SIFT (its commented twin)
+    bool akaze = false;                    // directory input: AKAZE + M-LDB rows (the reference's live extractor, NView:797) or SIFT (its commented twin,
+                                           // TwoView:112).  driver_main sets the default per program: NViewReconstruct AKAZE, TwoViewReconstruct SIFT
     double refine_px = 0.0;                // > 0: after BA, refine_structure(max_px) + a second BA (extension, not reference behaviour)
 };
 
@@ -366,6 +367,9 @@ inline int driver_main(int argc, char** argv, bool nview)
         return 0;
     }
     PipelineOptions opt;
+    // each program runs its reference's extractor + matcher unless told otherwise: NViewReconstuct.cpp is cv::AKAZE::create() +
+    // BFMatcher(NORM_HAMMING2) (NView:797, 876); TwoViewReconstruct.cpp is cv::SIFT::create(0, 3, 0.04, 10) + NORM_L2 (TwoView:112, 159)
+    opt.akaze = nview;
     int positional = 0;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];

@@ -29,7 +29,7 @@ with tempfile.TemporaryDirectory() as d:
             os.symlink(os.path.join(src, n), os.path.join(d, n))
     with open(os.path.join(d, "K.txt"), "w") as f:
         f.write("%.6f %.6f %.1f %.1f\n" % (28.0 / 36.0 * w, 28.0 / 36.0 * w, w / 2.0, h / 2.0))
-    subprocess.check_call([os.path.join(host, "NViewReconstruct"), d, d, "--features-only", "--max-features=%d" % nmax, "--save-features=" + out])
+    subprocess.check_call([os.path.join(host, "NViewReconstruct"), d, d, "--sift", "--features-only", "--max-features=%d" % nmax, "--save-features=" + out])
     print("wrote", out, os.path.getsize(out), "bytes")
     # the reference's live configuration: AKAZE key points + 61-byte M-LDB rows (sfm_akaze.hpp), matched under NORM_HAMMING2
     out = os.path.join(ROOT, "tests", "golden", "crazyhorse_features_akaze.bin")
