@@ -41,9 +41,8 @@ I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x bf16 dense (~2.5 PFLOP/s)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6: 256 CUs x 4 SIMD-32 x 2.4 GHz, one 32-bit lane-op per lane and cycle (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 # TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from separate rocprofv3 --pmc passes over this command at
 # N=1 / C4: recorded figures, NOT measured in the run that prints them (counters are not collectable in-process)
-# a write-only stream on this part (experiments/wbw*.hip, profiles/README.md): what a kernel that only stores can reach
-STORE_CEILING_GBS = 5760.0
-STORE_CEILING_SOURCE = "experiments/wbw4.hip: 400 MB write-only streams, best of the shapes tried (16-byte stores, 16k workgroups: 5.76 TB/s; the guide's 6.0-6.2 TB/s figure was not reproduced, profiles/README.md)"
+# what a kernel that only stores can reach is measured in the run itself: a 400 MB fill (one 16-byte store per thread, 4 KB per
+# workgroup -- the fastest write shape found, 6.6-6.9 TB/s sustained; devices differ by ~10 %, experiments/wbw4.hip, profiles/README.md)
 SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissection (the longest solver launch)
 RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (2.977e8, "profiles/r01_traffic_pmc.md"),
                     "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md"),
@@ -150,10 +149,21 @@ def main():
         qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
         alg = 4.0 * nq * nt + 4.0 * 128 * (nq + nt)          # 410.2 MB
         legs = {}
-        # The kernel's rate depends on how long the part has been writing at this rate: ~80 us per launch (5.1 TB/s) for the first ten
-        # launches after an idle gap, a 100-115 us transient, then 87-95 us sustained (experiments/distmat_sustained.py; a power-state
-        # effect, the same buffer returns to 80 us after 0.5 s of idle).  `ms` is the SUSTAINED figure (mean of launches 151..200 of a
-        # back-to-back run), `ms_burst` the first ten after 0.3 s of idle; every block of ten is listed.
+        # the write ceiling of THIS device: torch's fill of the same 400 MB, sustained (50 warm-up launches, mean of the next 100)
+        flat = torch.empty(nq * nt, dtype=torch.float32, device="cuda")
+        for _ in range(50):
+            flat.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(100):
+            flat.fill_(1.0)
+        e1.record(stream); torch.cuda.synchronize()
+        store_ceiling_gbs = 4.0 * nq * nt / (e0.elapsed_time(e1) / 100 * 1e-3) / 1e9
+        del flat
+        # `ms` is the SUSTAINED figure (mean of launches 151..200 of a back-to-back run), `ms_burst` the first ten after 0.3 s of idle;
+        # every block of ten is listed.  Round 2's 80 -> 110 -> 90 us curve came from the kernel's compute side (a pure writer holds its
+        # rate from the first launch, experiments/distmat_power.py): with the epilogue cut from ~19 to ~11 issue slots per element the
+        # kernel runs 80-82 us sustained, 4-5 us above its own store stream (experiments/distmat_modes.py).
         for name, ld in (("ld_10000", nt), ("ld_10016_rows_128B_aligned", 10016)):
             buf = torch.empty((nq, ld), dtype=torch.float32, device="cuda")
             out = buf[:, :nt]
@@ -173,13 +183,13 @@ def main():
             ms = sum(blocks[15:]) / 5.0
             legs[name] = dict(ms=ms, ms_burst=blocks[0], ms_per_block_of_10=[round(b, 4) for b in blocks],
                               achieved=alg / (ms * 1e-3) / 1e9, frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              frac_of_store_ceiling=alg / (ms * 1e-3) / 1e9 / STORE_CEILING_GBS,
+                              frac_of_store_ceiling=alg / (ms * 1e-3) / 1e9 / store_ceiling_gbs,
                               burst_achieved=alg / (blocks[0] * 1e-3) / 1e9, burst_frac=alg / (blocks[0] * 1e-3) / 1e9 / HBM_PEAK_GBS)
         ref = legs["ld_10000"]                                # the reference's layout (a dense cv::Mat: row stride = nt)
         tr, src = RECORDED_TRAFFIC["distmat_i8_kernel<4>"]
         gemm = dict(kernel="distmat_i8_kernel<4>", workload="10000x10000x128 float32 distance matrix", ms=ref["ms"],
                     bound="hbm", achieved=ref["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=ref["frac"], algorithmic_bytes=alg,
-                    store_ceiling_gbs=STORE_CEILING_GBS, store_ceiling_source=STORE_CEILING_SOURCE, legs=legs,
+                    store_ceiling_gbs=store_ceiling_gbs, store_ceiling_source="a 400 MB torch fill timed in this run, sustained (100 launches after 50): the write-only ceiling of this device", legs=legs,
                     traffic=tr, traffic_source=src + " (recorded by separate --pmc passes, not measured in this run)")
         del qs, ts
 
@@ -229,9 +239,11 @@ def main():
     b_it = 2 * 24 * n_obs + 2 * 24 * n_pt + 2 * 48 * n_img + 3 * 8 * n_red * n_red
 
     # ------------------------------------------------------------------ region B: matching
-    # C5 names 1000 images x 10k descriptors (999 pairs, 5 GB of float rows): the chain is generated on the host, so the
-    # bench matches its first 65 images (64 pairs of 10k x 10k x 128) -- the per-pair work is what the size changes
-    n_img_match = min(n_img, 65) if args.config == "C5" else n_img
+    # C5 names 1000 images x 10k descriptors (999 pairs, 5.1 GB of float rows): that chain is generated ON THE DEVICE (same
+    # construction, torch's random streams); the host-side copies that the CPU baseline and the from-host calls need are the
+    # first 13 images only
+    device_chain = args.config == "C5"
+    n_img_match = n_img
     m_steps = args.match_steps if args.match_steps > 0 else min(args.steps, 20)
     m_warm = min(args.warmup, 3)
     pairs_g, images, pairs_l = sdist.shard_pairs(n_img_match, rank, world)
@@ -239,10 +251,17 @@ def main():
     d_desc, sets = [], []
     if len(images) and not args.no_match:
         # descriptors of image i depend on image i-1: generate the chain up to this rank's last image
-        chain = synth.sift_descriptor_chain(images[-1] + 1, n_desc)
-        for i in images:
-            t = torch.from_numpy(chain[i]).cuda()
-            d_desc.append(t); sets.append(ctx.descset_l2(t))
+        if device_chain:
+            dchain = synth.sift_descriptor_chain_device(images[-1] + 1, n_desc)
+            chain = [t.cpu().numpy() for t in dchain[:13]] if rank == 0 else None
+            for i in images:
+                d_desc.append(dchain[i]); sets.append(ctx.descset_l2(dchain[i]))
+            del dchain
+        else:
+            chain = synth.sift_descriptor_chain(images[-1] + 1, n_desc)
+            for i in images:
+                t = torch.from_numpy(chain[i]).cuda()
+                d_desc.append(t); sets.append(ctx.descset_l2(t))
     n_pairs_l = 0 if args.no_match else pairs_l.shape[0]
     d_matches = torch.zeros((max(n_pairs_l, 1), n_desc, 4), dtype=torch.int32, device="cuda")
     d_counts = torch.zeros((max(n_pairs_l, 1),), dtype=torch.int32, device="cuda")
@@ -287,8 +306,14 @@ def main():
     # ------------------------------------------------------------------ region D: the same chain on binary rows (Hamming2)
     ham = None
     if not args.no_hamming and not args.no_match and n_pairs_l:
-        bchain = synth.akaze_descriptor_chain(images[-1] + 1, n_desc)
-        d_bin = [torch.from_numpy(bchain[i]).cuda() for i in images]
+        if device_chain:
+            dbchain = synth.akaze_descriptor_chain_device(images[-1] + 1, n_desc)
+            bchain = [t.cpu().numpy() for t in dbchain[:13]]
+            d_bin = [dbchain[i] for i in images]
+            del dbchain
+        else:
+            bchain = synth.akaze_descriptor_chain(images[-1] + 1, n_desc)
+            d_bin = [torch.from_numpy(bchain[i]).cuda() for i in images]
         bsets = [ctx.descset_hamming2(t) for t in d_bin]
 
         def ham_pass():
@@ -342,8 +367,9 @@ def main():
                 tc = time.perf_counter()
                 got = api.match_features_for_all(chain[:n_img_match], ctx=ctx)
                 mruns.append(1e3 * (time.perf_counter() - tc))
-            e2e["match_pairs_from_host"] = dict(ms=min(mruns[1:]), calls=[round(x, 3) for x in mruns], pairs=n_img_match - 1,
-                                                pairs_per_sec=(n_img_match - 1) / (min(mruns[1:]) * 1e-3), matches=int(sum(len(g) for g in got)),
+            n_host = min(len(chain), n_img_match)
+            e2e["match_pairs_from_host"] = dict(ms=min(mruns[1:]), calls=[round(x, 3) for x in mruns], pairs=n_host - 1,
+                                                pairs_per_sec=(n_host - 1) / (min(mruns[1:]) * 1e-3), matches=int(sum(len(g) for g in got)),
                                                 host_bytes_uploaded=int(sum(c.nbytes for c in chain[:n_img_match])),
                                                 what="match_features_for_all on host descriptor matrices: per image upload (pinned staging) + preparation, "
                                                      "one batched kNN-2 + ratio tail, match lists back on the host")
@@ -353,8 +379,8 @@ def main():
                     tc = time.perf_counter()
                     got = api.match_features_for_all(ham["chain"][:n_img_match], ctx=ctx)
                     hruns.append(1e3 * (time.perf_counter() - tc))
-                e2e["match_pairs_from_host_hamming2"] = dict(ms=min(hruns[1:]), calls=[round(x, 3) for x in hruns], pairs=n_img_match - 1,
-                                                             pairs_per_sec=(n_img_match - 1) / (min(hruns[1:]) * 1e-3), matches=int(sum(len(g) for g in got)))
+                e2e["match_pairs_from_host_hamming2"] = dict(ms=min(hruns[1:]), calls=[round(x, 3) for x in hruns], pairs=n_host - 1,
+                                                             pairs_per_sec=(n_host - 1) / (min(hruns[1:]) * 1e-3), matches=int(sum(len(g) for g in got)))
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, bounded sample)
     cpu = cpu4 = None
@@ -383,13 +409,13 @@ def main():
                 "scaling) and %d chain pairs of %dx%dx128 matching; oracle/ C restatement with OpenMP (an unoptimised "
                 "checker: 13-wide dual-number Jacobians, skyline Cholesky), not OpenCV/Ceres (unbuildable offline)")
         n_it_cpu = (30 if args.config == "C4" else 6) if big else 10          # ~10 s of CPU work at C4 (3 it/s on 16 threads)
-        cpu_pairs = min(100 if args.config != "C5" else 12, n_img_match - 1)
+        cpu_pairs = min(100 if args.config != "C5" else 12, n_img_match - 1, (len(chain) - 1) if chain is not None else 0)
         cpu = dict(value=cpu_ba(cores, n_it_cpu), unit="it/s", cores=cores, kind="port",
                    sample=("%d " % n_it_cpu) + what % (n_img, n_pt, cpu_pairs, n_desc, n_desc),
                    matched_pairs_per_sec=cpu_match(cores, cpu_pairs))
         # what the reference asks of Ceres: options.num_threads = 4 (NViewReconstuct.cpp:1218)
         n_it4 = (10 if args.config == "C4" else 3) if big else 10
-        pairs4 = min(25 if args.config != "C5" else 4, n_img_match - 1)
+        pairs4 = min(25 if args.config != "C5" else 4, n_img_match - 1, (len(chain) - 1) if chain is not None else 0)
         cpu4 = dict(value=cpu_ba(4, n_it4), unit="it/s", cores=4, kind="port",
                     sample=("%d " % n_it4) + what % (n_img, n_pt, pairs4, n_desc, n_desc),
                     matched_pairs_per_sec=cpu_match(4, pairs4))
@@ -402,7 +428,7 @@ def main():
                                    kind="port", what="oracle/ orc.ba_solve end to end (problem set-up + LM to the same termination rules), not Ceres")
         if ham is not None:
             orc.set_num_threads(cores)
-            hp = min(40 if args.config != "C5" else 6, n_img_match - 1)
+            hp = min(40 if args.config != "C5" else 6, n_img_match - 1, len(ham["chain"]) - 1)
             tc = time.perf_counter()
             for i in range(hp):
                 orc.match_features_hamming2(ham["chain"][i], ham["chain"][i + 1])

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfmhip.so")
+# SFMHIP_LIB: another build of the same library (experiments/: the -DSFMHIP_EXPERIMENTS build with its A/B knobs); never a fallback
+LIB_PATH = os.environ.get("SFMHIP_LIB") or os.path.join(_HERE, "libsfmhip.so")
 
 OK, E_ARG, E_HIP, E_COMM, E_NUMERIC, E_NODEVICE = 0, -1, -2, -3, -4, -5
 

@@ -1021,7 +1021,10 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         const double spec_radius = std::min(o.max_trust_region_radius, h->radius / (1.0 / 3.0));
         // folded: ba_back_reduce_kernel has parked this linearisation's cost and gradient maximum in d_back4[5..6] (the build below
         // overwrites the message tail they live in), and the exchange of the build sums d_back4[0..4] over the ranks
-        if (folded) { rc = enqueue_build(h, spec_radius, true, true, h->d_back4); if (rc) return rc; speculated = true; }
+        if (folded) {
+            read_pending_timing(h);         // the previous iteration's events, before this build re-records the event set they share
+            rc = enqueue_build(h, spec_radius, true, true, h->d_back4); if (rc) return rc; speculated = true;
+        }
         // one wave gathers the nine scalars into pinned host memory and bumps a sequence number the host polls; it also
         // re-arms the error flag.  The next build's zero-fill does not depend on the decision: it runs while the host decides.
         unsigned long long seq = h->pub_seq;

@@ -341,17 +341,17 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
     }
 }
 
-// Correctly rounded sqrtf for an integer-valued float in [0, 2^24): v_sqrt_f32 (<= 1 ulp) + the neighbour test of
-// LLVM's own f32 sqrt expansion, without its denormal scaling (x is 0 or >= 1).  Verified exhaustively against sqrtf
-// on the device (tests/test_match_gpu.py::test_exact_sqrt_all_integers).
+// Correctly rounded sqrtf for an integer-valued float in [0, 2^24): Markstein's fma correction on the reciprocal square root --
+// y = v_rsq_f32(x) (<= 1 ulp), g = x y, h = y / 2, d = x - g g (exact sign through the fma), result g + d h.  Five VALU issue
+// slots beside the transcendental (round 2's v_sqrt_f32 + neighbour test: eight); x = 0 goes through y = rsq(1).  Verified
+// against sqrtf for every integer < 2^24 on the device (tests/test_match_gpu.py::test_exact_sqrt_all_integers,
+// experiments/sqrt_variants.hip: the v_sqrt + rcp form of the same correction fails at 2^24 - 1).
 __device__ __forceinline__ float sqrt_exact_int(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = fmaf(-s_dn, s, x), r_up = fmaf(-s_up, s, x);
-    s = r_dn <= 0.0f ? s_dn : s;
-    s = r_up > 0.0f ? s_up : s;
-    return s;
+    const float y = __builtin_amdgcn_rsqf(fmaxf(x, 1.0f));
+    const float g = x * y, h = 0.5f * y;
+    const float d = fmaf(-g, g, x);
+    return fmaf(d, h, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -376,8 +376,11 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     constexpr int DP = 32 * KS;
     constexpr int CH = DP / 16;
     constexpr int PASSES = (128 * CH) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * DP + 2 * 128 * 4 + 4 * 32 * 36 * 4];
-    float* stage_out = (float*)(lds + 2 * 128 * DP + 2 * 128 * 4);
+    // one 128-row train block + its norms + a per-wave output slab: 35 KB at KS = 4, four workgroups per CU (the double-buffered
+    // form of round 2 took 51 KB = three; a workgroup works on ONE train block in the shipped configuration, so the second buffer
+    // bought nothing, and the write stream wants as many waves with stores in flight as it can get, profiles/README.md round 3)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[128 * DP + 128 * 4 + 4 * 32 * 36 * 4];
+    float* stage_out = (float*)(lds + 128 * DP + 128 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     // XCD-banded work mapping (speed only): workgroups are dealt round-robin to the 8 XCDs, so workgroup L works on the
@@ -406,9 +409,12 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         qfrag[ks] = *(const v4i*)(Q + (size_t)qrow_ld * DP + 32 * ks + 16 * half);
-    const int qn = qnorm[qrow_ld];
+    // d^2 = (|q|^2 + |t|^2) - 2 q.t in float: every term an integer below 2^24, so the add and the fma are exact -- one cvt, half a
+    // packed add and half a packed fma per element (the integer form: add, shift, subtract, cvt; an inline-asm v_mad_i32_i24 read the
+    // MFMA result without the wait states the hazard recogniser gives real instructions and returned stale values)
+    const float qn = (float)qnorm[qrow_ld];
 
-    int* lds_norm = (int*)(lds + 2 * 128 * DP);
+    float* lds_norm = (float*)(lds + 128 * DP);
     v4i stage[PASSES];
     int stage_norm = 0;
     auto g_load = [&](int blk) {
@@ -420,37 +426,32 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
         }
         if (tid < 128) { int tr = t_begin + blk * 128 + tid; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1); stage_norm = tnorm[tr]; }
     };
-    auto l_store = [&](int buf) {
+    auto l_store = [&]() {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
-            *(v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
+            *(v4i*)(lds + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
         }
-        if (tid < 128) lds_norm[buf * 128 + tid] = stage_norm;
+        if (tid < 128) lds_norm[tid] = (float)stage_norm;
     };
 
-    g_load(0); l_store(0);
+    g_load(0); l_store();
     __syncthreads();
     for (int blk = 0; blk < nblocks; ++blk) {
-        const int buf = blk & 1;
         if (blk + 1 < nblocks) g_load(blk + 1);
-        // all four 32-train tiles of the block first: four independent MFMA chains in flight, then four epilogues
-        v16i accs[4];
+        // tile by tile: one 16-register accumulator live at a time (<= 128 VGPRs = four waves per SIMD; the other waves' stores and
+        // epilogues cover this wave's MFMA latency, which round 2 covered with four chains in flight at three waves per SIMD)
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int r = tile * 32 + l31;
             v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (!(exp_mode & 16))           // 16: store-only experiment (no matrix products)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int c = 2 * ks + half;
-                const v4i a = *(const v4i*)(lds + buf * 128 * DP + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
+                const v4i a = *(const v4i*)(lds + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1))));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qfrag[ks], acc, 0, 0, 0);
             }
-            accs[tile] = acc;
-        }
-#pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            const v16i acc = accs[tile];
             // C[row = train (reg), col = query (lane&31)]: regs 4g..4g+3 <-> trains 8g + 4 half + {0,1,2,3}.
             // The tile goes through a per-wave LDS slab [32 queries][36 floats] so that every global store instruction
             // writes 8 query rows x 128 contiguous bytes (full cache lines) instead of 32 scattered 32-byte pieces.
@@ -458,22 +459,14 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int tl = tile * 32 + 8 * g + 4 * half;
-                const v4i tn = *(const v4i*)(lds_norm + buf * 128 + tl);
+                const float4 tn = *(const float4*)(lds_norm + tl);
                 float4 o;
-                if (exp_mode & 1) {
-                    o.x = (float)(qn + tn.x - 2 * acc[4 * g + 0]); o.y = (float)(qn + tn.y - 2 * acc[4 * g + 1]);
-                    o.z = (float)(qn + tn.z - 2 * acc[4 * g + 2]); o.w = (float)(qn + tn.w - 2 * acc[4 * g + 3]);
-                } else if (exp_mode & 4) {
-                o.x = sqrtf((float)(qn + tn.x - 2 * acc[4 * g + 0]));
-                o.y = sqrtf((float)(qn + tn.y - 2 * acc[4 * g + 1]));
-                o.z = sqrtf((float)(qn + tn.z - 2 * acc[4 * g + 2]));
-                o.w = sqrtf((float)(qn + tn.w - 2 * acc[4 * g + 3]));
-                } else {
-                o.x = sqrt_exact_int((float)(qn + tn.x - 2 * acc[4 * g + 0]));
-                o.y = sqrt_exact_int((float)(qn + tn.y - 2 * acc[4 * g + 1]));
-                o.z = sqrt_exact_int((float)(qn + tn.z - 2 * acc[4 * g + 2]));
-                o.w = sqrt_exact_int((float)(qn + tn.w - 2 * acc[4 * g + 3]));
-                }
+                o.x = fmaf(-2.0f, (float)acc[4 * g + 0], qn + tn.x); o.y = fmaf(-2.0f, (float)acc[4 * g + 1], qn + tn.y);
+                o.z = fmaf(-2.0f, (float)acc[4 * g + 2], qn + tn.z); o.w = fmaf(-2.0f, (float)acc[4 * g + 3], qn + tn.w);
+                if (exp_mode & 16) { o.x = tn.x; o.y = tn.y; o.z = tn.z; o.w = qn; }
+                else if (exp_mode & 1) { }
+                else if (exp_mode & 4) { o.x = sqrtf(o.x); o.y = sqrtf(o.y); o.z = sqrtf(o.z); o.w = sqrtf(o.w); }
+                else { o.x = sqrt_exact_int(o.x); o.y = sqrt_exact_int(o.y); o.z = sqrt_exact_int(o.z); o.w = sqrt_exact_int(o.w); }
                 *(float4*)(slab + l31 * 36 + 8 * g + 4 * half) = o;
             }
             const int tg0 = t_begin + blk * 128 + tile * 32;
@@ -495,8 +488,7 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
                 }
             }
         }
-        if (blk + 1 < nblocks) l_store(buf ^ 1);
-        __syncthreads();
+        if (blk + 1 < nblocks) { __syncthreads(); l_store(); __syncthreads(); }      // (more than one block per workgroup: experiments only)
     }
 }
 

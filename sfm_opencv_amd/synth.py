@@ -49,6 +49,58 @@ def sift_descriptor_chain(n_img, n_desc, dim=128, seed=SEED, overlap=0.6):
     return out
 
 
+def sift_descriptor_chain_device(n_img, n_desc, dim=128, seed=SEED, overlap=0.6, device="cuda"):
+    """The construction of sift_descriptor_chain with torch on the device (its own random streams: same distribution, not the same
+    numbers) -- for chains too large to generate on the host in bench time (C5: 1000 x 10000 x 128 floats = 5.1 GB)."""
+    import torch
+    g = torch.Generator(device=device)
+
+    def sift_like(n):
+        v = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32).abs_()
+        v /= torch.linalg.vector_norm(v, dim=1, keepdim=True)
+        v.clamp_(max=0.2)
+        v /= torch.linalg.vector_norm(v, dim=1, keepdim=True)
+        return torch.clamp(torch.floor(512.0 * v), max=255.0)
+
+    out, prev = [], None
+    n_copy = int(round(overlap * n_desc))
+    for i in range(n_img):
+        g.manual_seed(seed + i)
+        if prev is None:
+            cur = sift_like(n_desc)
+        else:
+            src = torch.randperm(n_desc, generator=g, device=device)[:n_copy]
+            noise = torch.randint(-2, 3, (n_copy, dim), generator=g, device=device).to(torch.float32)
+            copied = torch.clamp(prev[src] + noise, 0.0, 255.0)
+            cur = torch.cat([copied, sift_like(n_desc - n_copy)], 0)[torch.randperm(n_desc, generator=g, device=device)]
+        out.append(cur.contiguous())
+        prev = cur
+    return out
+
+
+def akaze_descriptor_chain_device(n_img, n_desc, nbytes=61, seed=SEED, overlap=0.6, flip=0.03, device="cuda"):
+    """akaze_descriptor_chain's construction with torch on the device (own random streams)."""
+    import torch
+    g = torch.Generator(device=device)
+    out, prev = [], None
+    n_copy = int(round(overlap * n_desc))
+    w = (2 ** torch.arange(8, device=device, dtype=torch.int32)).view(1, 1, 8)
+    for i in range(n_img):
+        g.manual_seed(seed + 7919 + i)
+        if prev is None:
+            cur = torch.randint(0, 256, (n_desc, nbytes), generator=g, device=device, dtype=torch.int32).to(torch.uint8)
+        else:
+            src = torch.randperm(n_desc, generator=g, device=device)[:n_copy]
+            bits = (torch.rand((n_copy, nbytes, 8), generator=g, device=device) < flip).to(torch.int32)
+            mask = (bits * w).sum(2).to(torch.uint8)
+            copied = prev[src] ^ mask
+            fresh = torch.randint(0, 256, (n_desc - n_copy, nbytes), generator=g, device=device, dtype=torch.int32).to(torch.uint8)
+            cur = torch.cat([copied, fresh], 0)[torch.randperm(n_desc, generator=g, device=device)]
+        out.append(cur.contiguous())
+        prev = cur
+    return out
+
+
 def akaze_descriptor_chain(n_img, n_desc, nbytes=61, seed=SEED, overlap=0.6, flip=0.03):
     """Binary (AKAZE MLDB-486-like) rows: 61 random bytes; copies get 3 % of their bits flipped."""
     out = []
