@@ -613,6 +613,13 @@ __global__ __launch_bounds__(256) void knn2_exact_f32_kernel(const PairDesc* __r
     }
 }
 
+__device__ __forceinline__ int bcnt_acc(unsigned x, int acc)
+{
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hamming2 kNN-2 (cv::NORM_HAMMING2 on CV_8U rows: number of non-zero 2-bit cells of a^b).
 // thread = query row (16 dwords in registers), train rows streamed through the scalar path
@@ -638,10 +645,12 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt) t_end = pd.nt;
     int best1 = INT_MAX, best2 = INT_MAX;
     // rows are [L0..L7 | H0..H7] (prep_hamming_kernel): q0,q1 = low-bit dwords, q2,q3 = high-bit dwords
-#define H2(ql, tl, qh, th) __popc(((ql) ^ (tl)) | ((qh) ^ (th)))
+    // popcount with accumulate (v_bcnt_u32_b32 d, x, acc) in two chains of four: hipcc turns a sum of __popc into eight plain counts
+    // + three v_add3 (11 instructions for 8 dwords; this: 8 + 1), and the kernel runs at the VALU issue rate (profiles/README.md, round 3)
+#define H2X(ql, tl, qh, th) (((ql) ^ (tl)) | ((qh) ^ (th)))
 #define ROW_DIST(t0, t1, t2, t3)                                                                                                   \
-    (H2(q0.x, t0.x, q2.x, t2.x) + H2(q0.y, t0.y, q2.y, t2.y) + H2(q0.z, t0.z, q2.z, t2.z) + H2(q0.w, t0.w, q2.w, t2.w)             \
-   + H2(q1.x, t1.x, q3.x, t3.x) + H2(q1.y, t1.y, q3.y, t3.y) + H2(q1.z, t1.z, q3.z, t3.z) + H2(q1.w, t1.w, q3.w, t3.w))
+    (bcnt_acc(H2X(q0.w, t0.w, q2.w, t2.w), bcnt_acc(H2X(q0.z, t0.z, q2.z, t2.z), bcnt_acc(H2X(q0.y, t0.y, q2.y, t2.y), bcnt_acc(H2X(q0.x, t0.x, q2.x, t2.x), 0)))) \
+   + bcnt_acc(H2X(q1.w, t1.w, q3.w, t3.w), bcnt_acc(H2X(q1.z, t1.z, q3.z, t3.z), bcnt_acc(H2X(q1.y, t1.y, q3.y, t3.y), bcnt_acc(H2X(q1.x, t1.x, q3.x, t3.x), 0)))))
 #define TOP2(d, jrel)                                                                                                              \
     do {                                                                                                                           \
         const int key = ((d) << 22) | (jrel);                                                                                      \
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
     }
 #undef TOP2
 #undef ROW_DIST
-#undef H2
+#undef H2X
     if (row < pd.nq_pad) {
         long long k1 = KEY_INVALID, k2 = KEY_INVALID;
         if (best1 != INT_MAX) k1 = ((long long)(best1 >> 22) << 32) | (unsigned int)(t_begin + (best1 & 0x3fffff));
