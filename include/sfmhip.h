@@ -254,6 +254,13 @@ int  sfmhip_rccl_comm_create(sfmhip_ctx*, const void* id128, int rank, int world
 int  sfmhip_rccl_comm_destroy(void* comm);
 int  sfmhip_ba_set_rccl(sfmhip_ba*, void* comm, int rank, int world);
 int  sfmhip_rccl_allreduce_f64(sfmhip_ctx*, void* comm, void* d_buf, size_t count);
+/* bundle_adjustment (NView:1162-1244) on several GPUs of ONE process -- what a C++ caller like the reference's main() uses: one context per
+ * device, same arguments and in-place semantics as sfmhip_ba_solve.  The points are sharded by first camera over the contexts, one host
+ * thread per context builds and runs its shard, the reduced-system message is summed by RCCL; where two contexts share a device (one-card
+ * rehearsal) or librccl is missing, by a host-staged exchange inside the process.  n_ctx = 1 is sfmhip_ba_solve. */
+int  sfmhip_ba_solve_multi(sfmhip_ctx* const* ctxs, int n_ctx, double* intrinsic4, double* ext6, int n_cam, double* pts, int n_pt,
+                           const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
+                           const sfm_ba_options* opts, sfm_ba_summary* summary);
 /* run the LM loop to termination */
 int  sfmhip_ba_run(sfmhip_ba*, sfm_ba_summary* summary);
 /* run exactly n_iter LM iterations (tolerance checks disabled); state carries over between calls */

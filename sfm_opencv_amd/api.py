@@ -360,6 +360,21 @@ class BAProblem:
             pass
 
 
+def ba_solve_multi(ctxs, K4, ext, pts, obs_cam, obs_pt, obs_uv, opts=None):
+    """sfmhip_ba_solve_multi on copies: one context per GPU of this process (two contexts on one device: host-staged rehearsal).
+    Returns (K4, ext, pts, summary dict)."""
+    K4 = np.array(K4, np.float64).reshape(4).copy(); ext = np.array(ext, np.float64).reshape(-1, 6).copy()
+    pts = np.array(pts, np.float64).reshape(-1, 3).copy()
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    uv = np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2)
+    o = opts if opts is not None else ctxs[0].ba_options()
+    s = BASummary()
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    ctxs[0]._check(ctxs[0].lib.sfmhip_ba_solve_multi(arr, len(ctxs), K4.ctypes.data, ext.ctypes.data, ext.shape[0], pts.ctypes.data, pts.shape[0],
+                                                      oc.ctypes.data, op.ctypes.data, uv.ctypes.data, oc.shape[0], C.byref(o), C.byref(s)))
+    return K4, ext, pts, s.asdict()
+
+
 def ratio_filter(idx2, dist2, ratio=0.6, floor_=10.0, mult=5.0):
     """sfmhip_ratio_filter (host C, needs no GPU): the tail of match_features, NViewReconstuct.cpp:880-908."""
     lib = _lib.load()

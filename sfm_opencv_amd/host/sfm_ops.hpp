@@ -58,6 +58,28 @@ inline sfmhip_ctx* context(int device = 0)
     return ctx;
 }
 
+// Devices bundle_adjustment() spreads its points over (one context each; the reduced-system sums go over RCCL inside the library,
+// sfmhip_ba_solve_multi).  Default: the one context above.  Listing a device twice gives two contexts on it: the one-card rehearsal.
+inline std::vector<sfmhip_ctx*>& ba_contexts()
+{
+    static std::vector<sfmhip_ctx*> v;
+    return v;
+}
+inline bool set_ba_devices(const std::vector<int>& devices)
+{
+    std::vector<sfmhip_ctx*>& v = ba_contexts();
+    for (size_t i = 1; i < v.size(); ++i) sfmhip_destroy(v[i]);
+    v.clear();
+    for (size_t i = 0; i < devices.size(); ++i) {
+        sfmhip_ctx* c = nullptr;
+        if (i == 0) c = context(devices[0]);
+        else if (sfmhip_create(devices[i], &c) != SFMHIP_OK) c = nullptr;
+        if (!c) { printf("[Err]: no context on device %d\n", devices[i]); for (size_t k = 1; k < v.size(); ++k) sfmhip_destroy(v[k]); v.clear(); return false; }
+        v.push_back(c);
+    }
+    return true;
+}
+
 // ---- matching (NView:873-913, 850-871) ---------------------------------------------------------------------------
 // CV_8U rows -> NORM_HAMMING2 (the live configuration, NView:876); CV_32F rows -> NORM_L2 (TwoViewReconstruct.cpp:159)
 inline void match_features(const Mat& query, const Mat& train, std::vector<DMatch>& matches)
@@ -273,8 +295,12 @@ inline void bundle_adjustment(Mat& intrinsic, std::vector<Mat>& extrinsics, std:
     for (int c = 0; c < nc; ++c) std::memcpy(&ext[6 * (size_t)c], extrinsics[c].ptr<double>(), 6 * sizeof(double));
     sfm_ba_options o; sfmhip_ba_default_options(&o);
     sfm_ba_summary s; std::memset(&s, 0, sizeof s);
-    const int rc = sfmhip_ba_solve(ctx, intrinsic.ptr<double>(), ext.data(), nc, pts3d.empty() ? nullptr : &pts3d[0].x, (int)pts3d.size(),
-                                   oc.data(), op.data(), uv.data(), (int)oc.size(), &o, &s);
+    const std::vector<sfmhip_ctx*>& many = ba_contexts();
+    const int rc = many.size() > 1
+        ? sfmhip_ba_solve_multi(many.data(), (int)many.size(), intrinsic.ptr<double>(), ext.data(), nc, pts3d.empty() ? nullptr : &pts3d[0].x,
+                                (int)pts3d.size(), oc.data(), op.data(), uv.data(), (int)oc.size(), &o, &s)
+        : sfmhip_ba_solve(ctx, intrinsic.ptr<double>(), ext.data(), nc, pts3d.empty() ? nullptr : &pts3d[0].x, (int)pts3d.size(),
+                          oc.data(), op.data(), uv.data(), (int)oc.size(), &o, &s);
     if (rc != SFMHIP_OK || s.termination == SFMHIP_BA_FAILURE) { printf("Bundle Adjustment failed.\n"); return; }
     for (int c = 0; c < nc; ++c) std::memcpy(extrinsics[c].ptr<double>(), &ext[6 * (size_t)c], 6 * sizeof(double));
     printf("\nBundle Adjustment statistics (approximated RMSE):\n #views: %d\n #residuals: %d\n Initial RMSE(pixel): %g\n"

@@ -363,7 +363,7 @@ inline int run_twoview(Features& f, const PipelineOptions& opt)
 inline int driver_main(int argc, char** argv, bool nview)
 {
     if (argc < 2 || std::string(argv[1]).empty()) {
-        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.jpg | .ppm | .pgm, K.txt beside them) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--akaze | --sift] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
+        printf("[Warning]: empty dataset path.\nusage: %s <image directory (.jpg | .ppm | .pgm, K.txt beside them) | features file> [output dir = ../Viewer] [--poses-from-file] [--write-back-poses] [--quiet] [--akaze | --sift] [--gpus=DEV,DEV,...] [--max-features=N] [--save-features=FILE] [--features-only] [--refine[=PX]]\n", argv[0]);
         return 0;
     }
     PipelineOptions opt;
@@ -377,6 +377,11 @@ inline int driver_main(int argc, char** argv, bool nview)
         else if (a == "--write-back-poses") opt.write_back_poses = true;
         else if (a == "--quiet") opt.print_offsets = false;
         else if (a == "--features-only") opt.features_only = true;
+        else if (a.rfind("--gpus=", 0) == 0) {          // bundle adjustment over several devices of this process: --gpus=0,1,2,3
+            std::vector<int> devs;
+            for (size_t at = 7; at < a.size();) { size_t e = a.find(',', at); if (e == std::string::npos) e = a.size(); devs.push_back(std::atoi(a.substr(at, e - at).c_str())); at = e + 1; }
+            if (devs.empty() || !set_ba_devices(devs)) return 1;
+        }
         else if (a == "--akaze") opt.akaze = true;
         else if (a == "--sift") opt.akaze = false;
         else if (a.rfind("--max-features=", 0) == 0) opt.max_features = std::atoi(a.c_str() + 15);

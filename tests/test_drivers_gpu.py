@@ -259,3 +259,20 @@ def test_nview_driver_on_crazyhorse_with_akaze_rows(drivers, tmp_path):
     assert all(b > a for a, b in zip(yaw, yaw[1:])) and 5 < yaw[-1] < 40          # the same sweep the SIFT run recovers
     z = y1["points"][:, 2]
     assert np.median(z) > 2 and (z > 0).mean() > 0.9
+
+
+def test_nview_driver_spreads_bundle_adjustment_over_contexts(drivers, tmp_path):
+    """`NViewReconstruct ... --gpus=0,0`: bundle_adjustment() of the C++ driver over two contexts (the one-card rehearsal of a
+    multi-GPU process: points sharded by first camera, one thread per context, the sums exchanged inside the library) must write
+    the structure the single-context run writes."""
+    feat = os.path.join(GOLD, "crazyhorse_features.bin")
+    a = tmp_path / "one"; b = tmp_path / "two"; a.mkdir(); b.mkdir()
+    # SIFT-rows fixture; extractor flags do not matter for a features file
+    o1 = subprocess.run([drivers[0], feat, str(a), "--quiet"], capture_output=True, text=True)
+    o2 = subprocess.run([drivers[0], feat, str(b), "--quiet", "--gpus=0,0"], capture_output=True, text=True)
+    assert o1.returncode == 0 and o2.returncode == 0, o2.stdout[-2000:] + o2.stderr[-2000:]
+    r = re.compile(r"Final   RMSE\(pixel\): ([0-9.eE+-]+)")
+    f1, f2 = float(r.search(o1.stdout).group(1)), float(r.search(o2.stdout).group(1))
+    assert abs(f1 - f2) <= 1e-4 * f1, (f1, f2)
+    y1 = formats.read_structure_yml(a / "structure_ba.yml"); y2 = formats.read_structure_yml(b / "structure_ba.yml")
+    assert y1["points"].shape == y2["points"].shape and np.abs(y1["points"] - y2["points"]).max() <= 1e-3 * max(1.0, np.abs(y1["points"]).max())
