@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--config", default="C4", choices=["C3", "C4", "C5", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm", action="store_true")
+    ap.add_argument("--generator", default="mt19937_64", choices=["mt19937_64", "numpy"],
+                    help="synthetic inputs: SURVEY 8d's std::mt19937_64 generators (libsfmsynth.so) or the numpy PCG64 ones the tests use")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip region C (the drop-in calls from host arrays)")
     ap.add_argument("--no-hamming", action="store_true", help="skip region D (Hamming2 chain)")
@@ -124,6 +126,10 @@ def main():
     ctx = api.Context(local, use_torch_stream=True)
     stream = ctx.torch_stream
 
+    mt = args.generator == "mt19937_64"
+    gen_scene = synth.ba_scene_mt if mt else synth.ba_scene
+    gen_sift = synth.sift_descriptor_chain_mt if mt else synth.sift_descriptor_chain
+    gen_akaze = synth.akaze_descriptor_chain_mt if mt else synth.akaze_descriptor_chain
     cfg = dict(synth.CONFIGS[args.config]) if args.config in synth.CONFIGS else dict(n_img=12, n_desc=1000, n_pt=5000)
     n_img, n_desc, n_pt = cfg["n_img"], cfg["n_desc"], cfg["n_pt"]
 
@@ -144,7 +150,7 @@ def main():
     gemm = None
     if not args.no_gemm and rank == 0:
         nq = nt = 10000
-        dd = synth.sift_descriptor_chain(2, nq, seed=synth.SEED + 100000)
+        dd = gen_sift(2, nq, seed=synth.SEED + 100000)
         q = torch.from_numpy(dd[0]).cuda(); t = torch.from_numpy(dd[1]).cuda()
         qs, ts = ctx.descset_l2(q), ctx.descset_l2(t)
         alg = 4.0 * nq * nt + 4.0 * 128 * (nq + nt)          # 410.2 MB
@@ -194,7 +200,7 @@ def main():
         del qs, ts
 
     # ------------------------------------------------------------------ region A: bundle adjustment
-    sc = synth.ba_scene(n_img, n_pt)
+    sc = gen_scene(n_img, n_pt)
     pts_l, oc_l, op_l, uv_l, _ = sdist.shard_points(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["pts0"], rank, world)
     pb = ctx.ba_create(sc["K0"], sc["ext0"], pts_l, oc_l, op_l, uv_l)
     native_comm = None
@@ -258,7 +264,7 @@ def main():
                 d_desc.append(dchain[i]); sets.append(ctx.descset_l2(dchain[i]))
             del dchain
         else:
-            chain = synth.sift_descriptor_chain(images[-1] + 1, n_desc)
+            chain = gen_sift(images[-1] + 1, n_desc)
             for i in images:
                 t = torch.from_numpy(chain[i]).cuda()
                 d_desc.append(t); sets.append(ctx.descset_l2(t))
@@ -312,7 +318,7 @@ def main():
             d_bin = [dbchain[i] for i in images]
             del dbchain
         else:
-            bchain = synth.akaze_descriptor_chain(images[-1] + 1, n_desc)
+            bchain = gen_akaze(images[-1] + 1, n_desc)
             d_bin = [torch.from_numpy(bchain[i]).cuda() for i in images]
         bsets = [ctx.descset_hamming2(t) for t in d_bin]
 
@@ -399,7 +405,7 @@ def main():
             if args.no_match or n_pairs_cpu <= 0:
                 return None
             orc.set_num_threads(threads)
-            ch = chain if chain is not None and len(chain) > n_pairs_cpu else synth.sift_descriptor_chain(n_pairs_cpu + 1, n_desc)
+            ch = chain if chain is not None and len(chain) > n_pairs_cpu else gen_sift(n_pairs_cpu + 1, n_desc)
             tc = time.perf_counter()
             for i in range(n_pairs_cpu):
                 orc.match_features_l2(ch[i], ch[i + 1])
@@ -520,7 +526,8 @@ def main():
         out = {
             "metric": "ba_iterations_per_sec", "value": ba_its, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_ba / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (SURVEY 8d constructions; " + ("std::mt19937_64, seed 20240607 + i" if mt else "numpy PCG64, seed 20240607 + i") + (", C5 descriptor chain: torch generator on the device" if device_chain else "") + ")",
             "config": {"workload": f"{args.config}: {n_img} images x {n_desc} SIFT-like descriptors ({n_img_match - 1} chain pairs matched), "
                                    f"{n_img} cameras / {n_pt} points / {n_obs} observations BA",
                        "parallelism": f"points (by first camera) + pairs sharded over {world} rank(s), cameras replicated, 1 all-reduce per LM iteration (packed reduced-system "

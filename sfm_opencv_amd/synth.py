@@ -231,3 +231,59 @@ def two_view_scene(n, seed=SEED, noise_px=0.3):
     xy1 = (proj(R1, T1) + noise_px * rng.standard_normal((n, 2))).astype(np.float32)
     xy2 = (proj(R2, T2) + noise_px * rng.standard_normal((n, 2))).astype(np.float32)
     return dict(K=Kfull, R1=R1, T1=T1, R2=R2, T2=T2, X=X, xy1=xy1, xy2=xy2)
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8d names std::mt19937_64 (seed 20240607 + i): the same constructions in C++ (host/sfm_synth.cpp -> libsfmsynth.so).
+# bench.py uses these; the tests keep the numpy streams above, whose scenes their fixed expectations were written for.
+# ------------------------------------------------------------------------------------------------
+_synth_lib = None
+
+
+def _mt_lib():
+    global _synth_lib
+    if _synth_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmsynth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: make -C sfm_opencv_amd/host (or __graft_entry__.build())")
+        lib = C.CDLL(path)
+        lib.sfmsynth_sift_chain.restype = C.c_int
+        lib.sfmsynth_sift_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_void_p]
+        lib.sfmsynth_akaze_chain.restype = C.c_int
+        lib.sfmsynth_akaze_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_void_p]
+        lib.sfmsynth_ba_scene.restype = C.c_longlong
+        lib.sfmsynth_ba_scene.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 9
+        _synth_lib = lib
+    return _synth_lib
+
+
+def sift_descriptor_chain_mt(n_img, n_desc, dim=128, seed=SEED, overlap=0.6):
+    """sift_descriptor_chain on std::mt19937_64 (seed + i per image), generated by libsfmsynth.so"""
+    out = np.empty((n_img, n_desc, dim), np.float32)
+    if _mt_lib().sfmsynth_sift_chain(n_img, n_desc, dim, seed, overlap, out.ctypes.data) != 0:
+        raise RuntimeError("sfmsynth_sift_chain failed")
+    return [out[i] for i in range(n_img)]
+
+
+def akaze_descriptor_chain_mt(n_img, n_desc, nbytes=61, seed=SEED, overlap=0.6, flip=0.03):
+    out = np.empty((n_img, n_desc, nbytes), np.uint8)
+    if _mt_lib().sfmsynth_akaze_chain(n_img, n_desc, nbytes, seed, overlap, flip, out.ctypes.data) != 0:
+        raise RuntimeError("sfmsynth_akaze_chain failed")
+    return [out[i] for i in range(n_img)]
+
+
+def ba_scene_mt(n_cam, n_pt, seed=SEED, noise_px=0.5, outlier_frac=0.02, min_len=2, max_len=6):
+    """ba_scene on std::mt19937_64: same construction and the same dict"""
+    lib = _mt_lib()
+    null = None
+    n_obs = lib.sfmsynth_ba_scene(n_cam, n_pt, seed, noise_px, outlier_frac, min_len, max_len, *([null] * 9))
+    if n_obs < 0:
+        raise RuntimeError("sfmsynth_ba_scene failed")
+    Kt = np.empty(4); et = np.empty((n_cam, 6)); pt = np.empty((n_pt, 3)); K0 = np.empty(4); e0 = np.empty((n_cam, 6)); p0 = np.empty((n_pt, 3))
+    oc = np.empty(n_obs, np.int32); op = np.empty(n_obs, np.int32); uv = np.empty((n_obs, 2))
+    got = lib.sfmsynth_ba_scene(n_cam, n_pt, seed, noise_px, outlier_frac, min_len, max_len, Kt.ctypes.data, et.ctypes.data, pt.ctypes.data,
+                                K0.ctypes.data, e0.ctypes.data, p0.ctypes.data, oc.ctypes.data, op.ctypes.data, uv.ctypes.data)
+    assert got == n_obs
+    return dict(K_true=Kt, ext_true=et, pts_true=pt, K0=K0, ext0=e0, pts0=p0, obs_cam=oc, obs_pt=op, obs_uv=uv, n_cam=n_cam, n_pt=n_pt, n_obs=int(n_obs))
