@@ -207,8 +207,18 @@ def main():
     if world > 1:
         # production: the in-library RCCL hook (ncclAllReduce on the context's stream, no Python between the LM loop and the
         # collective).  gloo rehearsals (several ranks on one card, SFM_DIST_BACKEND=gloo) go through torch.distributed instead.
-        if dist.get_backend() == "nccl" and ctx.rccl_available() and os.environ.get("SFM_NATIVE_RCCL", "1") != "0":
-            native_comm = sdist.make_native_rccl(ctx)
+        want_native = dist.get_backend() == "nccl" and ctx.rccl_available() and os.environ.get("SFM_NATIVE_RCCL", "1") != "0"
+        if want_native:
+            try:
+                native_comm = sdist.make_native_rccl(ctx)
+            except Exception as exc:       # e.g. a second RCCL copy that cannot initialise: every rank must then take the same other path
+                print(f"[bench] rank {rank}: in-library RCCL communicator failed ({exc}); falling back to the torch.distributed hook", file=sys.stderr)
+                native_comm = None
+            ok = torch.tensor([1 if native_comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and native_comm is not None:
+                ctx.rccl_comm_destroy(native_comm); native_comm = None
+        if native_comm is not None:
             pb.set_rccl(native_comm, rank, world)
         else:
             pb.set_allreduce(sdist.make_allreduce_hook(), rank, world)
