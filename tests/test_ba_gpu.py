@@ -483,3 +483,21 @@ def test_single_process_multi_context_solve_matches_the_single_gpu_call(ctx, sha
     assert np.abs(ext - extr).max() <= 1e-3 and np.abs(K - Kr).max() <= 1e-5 * np.abs(Kr).max() and np.abs(pts - ptsr).max() <= 1e-3
     assert np.array_equal(ext[0], sc["ext0"][0])                   # camera 0 stays constant on every rank
     assert s["total_time_s"] > 0
+
+
+def test_problem_memory_is_reused_across_solves_and_trim_releases_it(ctx):
+    """The context keeps the device blocks of destroyed problems (a hipFree of gigabytes stalls the following calls); reuse and
+    sfmhip_trim must not change results: the same solve three times, trimming in between, bit for bit."""
+    sc = synth.ba_scene(30, 20000)
+    outs = []
+    for rep in range(3):
+        K, ext, pts, s = ctx.ba_solve(*_args(sc))
+        outs.append((K, ext, pts, s["final_cost"], s["iterations"]))
+        if rep == 0:
+            ctx.trim()
+        big = synth.ba_scene(12, 300 + 100 * rep)                   # another problem size in between: different blocks come and go
+        ctx.ba_solve(*_args(big))
+    for o in outs[1:]:
+        assert o[3] == outs[0][3] and o[4] == outs[0][4]
+        for a, b in zip(o[:3], outs[0][:3]):
+            assert np.array_equal(a, b)

@@ -211,3 +211,33 @@ def test_match_lists_written_straight_to_pinned_host_memory(ctx):
         assert np.array_equal(d_m[p, :cnt[p]].cpu().numpy(), h_m[p, :cnt[p]].numpy())
         m = orc.match_features_l2(descs[p], descs[p + 1])
         assert np.array_equal(h_m[p, :cnt[p], 0].numpy(), m["queryIdx"]) and np.array_equal(h_m[p, :cnt[p], 1].numpy(), m["trainIdx"])
+
+
+def test_host_entry_points_strided_rows_large_uploads_and_block_reuse(ctx):
+    """Round 3: host rows go to HBM through a pinned staging ring (contiguous matrices) or a 2-D copy (row stride > row length, an
+    OpenCV ROI), the sets' device blocks come from the context's cache and go back to it, and the 'all values integers in [0, 255]'
+    flag of a batch of sets is resolved with one round trip.  None of that may change a match list."""
+    import ctypes as C
+    descs = synth.sift_descriptor_chain(3, 9000, seed=77)           # 4.6 MB per image: the staged (multi-threaded) upload path
+    want = [orc.match_features_l2(descs[i], descs[i + 1]) for i in range(2)]
+    for rep in range(3):                                            # blocks released by one round are reused by the next
+        got = api.match_features_for_all(descs, ctx=ctx)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        if rep == 1:
+            ctx.trim()                                              # give the idle blocks back to the driver in between
+    # strided rows through the C entry point: the matrices embedded in wider buffers
+    wide = [np.full((9000, 160), -7.0, np.float32) for _ in range(2)]
+    for k in range(2):
+        wide[k][:, 16:144] = descs[k]
+    out = np.zeros(9000, api.DMATCH); n = C.c_int()
+    rc = ctx.lib.sfmhip_match_features_l2(ctx.h, wide[0][:, 16:].ctypes.data, 9000, wide[1][:, 16:].ctypes.data, 9000, 128, 160, 160,
+                                          out.ctypes.data, C.byref(n))
+    assert rc == 0 and np.array_equal(out[:n.value], want[0])
+    # a set of general floats among integer-valued ones: the batch falls back to the exact path as a whole, same lists as the oracle
+    mixed = [descs[0][:700].copy(), descs[1][:700].copy()]
+    mixed[1][3, 5] += 0.25
+    g = api.match_features_for_all(mixed, ctx=ctx)[0]
+    assert np.array_equal(g, orc.match_features_l2(mixed[0], mixed[1]))
+    b = synth.akaze_descriptor_chain(2, 5000, seed=5)
+    assert np.array_equal(api.match_features_for_all(b, ctx=ctx)[0], orc.match_features_hamming2(b[0], b[1]))
