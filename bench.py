@@ -44,9 +44,10 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6: 256 CUs x 4 SIMD-3
 # what a kernel that only stores can reach is measured in the run itself: a 400 MB fill (one 16-byte store per thread, 4 KB per
 # workgroup -- the fastest write shape found, 6.6-6.9 TB/s sustained; devices differ by ~10 %, experiments/wbw4.hip, profiles/README.md)
 SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissection (the longest solver launch)
-RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (2.977e8, "profiles/r01_traffic_pmc.md"),
-                    "distmat_i8_kernel<4>": (4.378e8, "profiles/r01_traffic_pmc.md"),
-                    "ba_camschur_kernel": (9.734e7, "profiles/r02_traffic_pmc.md")}      # FETCH_SIZE + WRITE_SIZE raw (gathers: uncalibrated)
+RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (3.045e8, "profiles/r03_traffic_pmc.md"),
+                    "distmat_i8_kernel<4>": (4.881e8, "profiles/r03_traffic_pmc.md"),
+                    "knn2_hamming2_kernel": (6.368e8, "profiles/r03_traffic_pmc.md"),
+                    "ba_camschur_kernel": (9.94e7, "profiles/r03_traffic_pmc.md")}      # 2 x FETCH_SIZE (streaming reads; raw for gathers / scalar loads) + WRITE_SIZE
 
 
 def spawn_ranks(n, argv):
@@ -526,7 +527,10 @@ def main():
             roof_ham = {"kernel": "knn2_hamming2_kernel", "bound": "valu_int", "achieved": lane_ops / (ham_net * 1e-3) / 1e12,
                         "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": lane_ops / (ham_net * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
                         "algorithmic_ops": lane_ops, "avg_launch_ms": ham["kernel_ms"], "event_bracket_overhead_ms": ev_overhead_ms,
-                        "avg_launch_ms_net": ham_net, "launches_timed": int(ham["calls"]), "merge_ms": ham["merge_ms"], "traffic": None,
+                        "avg_launch_ms_net": ham_net, "launches_timed": int(ham["calls"]), "merge_ms": ham["merge_ms"],
+                        "traffic": RECORDED_TRAFFIC["knn2_hamming2_kernel"][0] if (world == 1 and args.config == "C4") else None,
+                        "traffic_source": (RECORDED_TRAFFIC["knn2_hamming2_kernel"][1] + " (recorded by separate --pmc passes, not measured in this run)") if (world == 1 and args.config == "C4") else None,
+                        "measured_issue_rate": "every VALU mix measured on this part sustains ~1.9 ns per instruction and SIMD (profiles/r03_valu_issue_rates.log): 28 instructions x 64 rows per wave put this kernel AT that rate; `peak` is the guide's 2-cycle figure",
                         "note": "one launch = all chain pairs of this rank; integer VALU work (xor / or / popcount), no matrix-core formulation "
                                 "of a two-bit-cell Hamming distance is exact; bytes are negligible (64 B per row)"}
             ham_out = {"value": (n_img_match - 1) * m_steps / ham["t"], "ms_per_pass": 1e3 * ham["t"] / m_steps, "pairs": n_img_match - 1,

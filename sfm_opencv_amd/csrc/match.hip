@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     v4i qfrag[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        qfrag[ks] = *(const v4i*)(Q + (size_t)qrow_ld * DP + 32 * ks + 16 * half);
+        qfrag[ks] = (exp_mode & 32) ? v4i{ 1, 2, 3, 4 } : *(const v4i*)(Q + (size_t)qrow_ld * DP + 32 * ks + 16 * half);      // 32: no operand loads (experiment)
     // d^2 = (|q|^2 + |t|^2) - 2 q.t in float: every term an integer below 2^24, so the add and the fma are exact -- one cvt, half a
     // packed add and half a packed fma per element (the integer form: add, shift, subtract, cvt; an inline-asm v_mad_i32_i24 read the
     // MFMA result without the wait states the hazard recogniser gives real instructions and returned stale values)
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
         for (int p = 0; p < PASSES; ++p) {
             const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
             int tr = t_begin + blk * 128 + r; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1);       // shifted windows reach 16 rows past either end
-            stage[p] = *(const v4i*)(T + (size_t)tr * DP + 16 * c);
+            stage[p] = (exp_mode & 32) ? v4i{ 1, 2, 3, 4 } : *(const v4i*)(T + (size_t)tr * DP + 16 * c);
         }
         if (tid < 128) { int tr = t_begin + blk * 128 + tid; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1); stage_norm = tnorm[tr]; }
     };
