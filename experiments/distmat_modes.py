@@ -29,9 +29,14 @@ for ld in (10000, 10016):
     for rep in range(2):
         us = sustained(lambda: flat.fill_(1.0))
         print(f"ld {ld}  torch fill of 400 MB (write ceiling of this device)   {us[0]:6.1f} {us[1]:6.1f} {us[2]:6.1f} us  -> {4e8 / us[2] / 1e6:.2f} TB/s", flush=True)
-        for mode, name in ((0, "distmat_i8_kernel (real)"), (1, "no sqrt (d^2 as float)"), (4, "plain sqrtf, no exactness fix-up"), (2, "compute only, no stores"),
+        for nwv in (("4", "8") if os.environ.get("DM_AB") else ("",)):
+          if nwv:
+            os.environ["SFMHIP_EXP_DM_NW"] = nwv; print("  -- waves per workgroup:", nwv)
+          for mode, name in ((0, "distmat_i8_kernel (real)"), (1, "no sqrt (d^2 as float)"), (4, "plain sqrtf, no exactness fix-up"), (2, "compute only, no stores"),
                            (16, "stores only, no MFMA / sqrt"), (16 | 32, "stores only, no operand loads either"), (32, "real kernel without operand loads"), (8, "real kernel, nontemporal stores")):
             os.environ["SFMHIP_EXP_DISTMAT"] = str(mode)
             us = sustained(lambda: ctx.l2_distance_matrix_dev(qs, ts, out))
             print(f"ld {ld}  mode {mode:2d} {name:36s} {us[0]:6.1f} {us[1]:6.1f} {us[2]:6.1f} us  -> {alg / us[2] / 1e6:.2f} TB/s", flush=True)
+            if nwv and mode == 4:
+                break
     del out, buf, flat

@@ -341,6 +341,8 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
     }
 }
 
+#define DISTMAT_WAVES 4
+
 // Correctly rounded sqrtf for an integer-valued float in [0, 2^24): Markstein's fma correction on the reciprocal square root --
 // y = v_rsq_f32(x) (<= 1 ulp), g = x y, h = y / 2, d = x - g g (exact sign through the fma), result g + d h.  Five VALU issue
 // slots beside the transcendental (round 2's v_sqrt_f32 + neighbour test: eight); x = 0 goes through y = rsq(1).  Verified
@@ -361,8 +363,8 @@ __device__ __forceinline__ float sqrt_exact_int(float x)
 // instructions complete a 128-byte line of each of the wave's 32 query rows.
 // grid = (query blocks of 128, train super-blocks of TB*128 rows), block = 256.
 // ------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
+template <int KS, int NW>          // NW waves per workgroup = 32 NW query rows against one 128-train block
+__global__ __launch_bounds__(64 * NW) void distmat_i8_kernel(const int8_t* __restrict__ Q, const int32_t* __restrict__ qnorm,
                                                          const int8_t* __restrict__ T, const int32_t* __restrict__ tnorm,
                                                          int nq, int nq_pad, int nt, int nt_pad, int blocks_per_wg,
                                                          float* __restrict__ dist, size_t ldd, int vec_ok, int parity_mode, int exp_mode_arg)
@@ -375,11 +377,12 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
 #endif
     constexpr int DP = 32 * KS;
     constexpr int CH = DP / 16;
-    constexpr int PASSES = (128 * CH) / 256;
+    constexpr int NT = 64 * NW, QROWS = 32 * NW;
+    constexpr int PASSES = (128 * CH + NT - 1) / NT;
     // one 128-row train block + its norms + a per-wave output slab: 35 KB at KS = 4, four workgroups per CU (the double-buffered
     // form of round 2 took 51 KB = three; a workgroup works on ONE train block in the shipped configuration, so the second buffer
     // bought nothing, and the write stream wants as many waves with stores in flight as it can get, profiles/README.md round 3)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[128 * DP + 128 * 4 + 4 * 32 * 36 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[128 * DP + 128 * 4 + NW * 32 * 36 * 4];
     float* stage_out = (float*)(lds + 128 * DP + 128 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -392,12 +395,12 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     // 128-B line): a workgroup takes 128 rows of ONE parity out of 256 consecutive ones and the odd ones shift their train
     // window 16 columns down, so that every 512-B row segment a wave stores starts on a line boundary and no line is
     // shared between two workgroups (93-103 us -> the aligned layout's 77-80 us at 10k x 10k, profiles/README.md).
-    const int n_qb = parity_mode ? 2 * ((nq + 255) >> 8) : (nq + 127) >> 7;
+    const int n_qb = parity_mode ? 2 * ((nq + 2 * QROWS - 1) / (2 * QROWS)) : (nq + QROWS - 1) / QROWS;
     const int n_tb = (nt_pad / 128 + (parity_mode ? 1 : 0) + blocks_per_wg - 1) / blocks_per_wg;
     const int L = blockIdx.x, slot = L >> 3;
     const int qb = (slot / n_tb) * 8 + (L & 7), tb = slot % n_tb;
     if (qb >= n_qb) return;
-    const int qbase = parity_mode ? (qb >> 1) * 256 + (qb & 1) : qb * 128, qstep = parity_mode ? 2 : 1;      // row i of the tile: qbase + qstep * i
+    const int qbase = parity_mode ? (qb >> 1) * (2 * QROWS) + (qb & 1) : qb * QROWS, qstep = parity_mode ? 2 : 1;      // row i of the tile: qbase + qstep * i
     const int q0i = wave * 32;
     const int t_begin = tb * blocks_per_wg * 128 - ((parity_mode && (qb & 1)) ? 16 : 0);
     int nblocks = (nt_pad - t_begin + 127) / 128; if (nblocks > blocks_per_wg) nblocks = blocks_per_wg;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     auto g_load = [&](int blk) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
+            const int cid = p * NT + tid, r = (cid / CH) & 127, c = cid % CH;
             int tr = t_begin + blk * 128 + r; tr = tr < 0 ? 0 : (tr < nt_pad ? tr : nt_pad - 1);       // shifted windows reach 16 rows past either end
             stage[p] = (exp_mode & 32) ? v4i{ 1, 2, 3, 4 } : *(const v4i*)(T + (size_t)tr * DP + 16 * c);
         }
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(256) void distmat_i8_kernel(const int8_t* __restric
     auto l_store = [&]() {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int cid = p * 256 + tid, r = cid / CH, c = cid % CH;
-            *(v4i*)(lds + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
+            const int cid = p * NT + tid, r = cid / CH, c = cid % CH;
+            if (cid < 128 * CH) *(v4i*)(lds + r * DP + 16 * (c ^ ((r >> 1) & (CH - 1)))) = stage[p];
         }
         if (tid < 128) lds_norm[tid] = (float)stage_norm;
     };
@@ -1346,12 +1349,23 @@ int sfmhip_l2_distance_matrix_dev(sfmhip_ctx* ctx, const sfmhip_descset* query, 
 #ifdef SFMHIP_EXPERIMENTS
         if (getenv("SFMHIP_EXP_NO_PARITY")) parity = 0;
 #endif
-        const int n_qb = parity ? 2 * ceil_div(query->rows, 256) : ceil_div(query->rows, 128), n_tb = ceil_div(train->rows_pad / 128 + (parity ? 1 : 0), bpw);
+        int nw = DISTMAT_WAVES;          // waves per workgroup: 32 nw query rows share one 128-train block
+#ifdef SFMHIP_EXPERIMENTS
+        if (const char* e = getenv("SFMHIP_EXP_DM_NW")) nw = atoi(e) == 8 ? 8 : 4;
+#endif
+        const int qrows = 32 * nw;
+        const int n_qb = parity ? 2 * ceil_div(query->rows, 2 * qrows) : ceil_div(query->rows, qrows), n_tb = ceil_div(train->rows_pad / 128 + (parity ? 1 : 0), bpw);
         const dim3 grid((unsigned)(8 * ceil_div(n_qb, 8) * n_tb));     // decoded in the kernel (XCD-banded mapping)
         const int ks = query->dim_pad / 32;
-#define DM_LAUNCH(K) hipLaunchKernelGGL(distmat_i8_kernel<K>, grid, dim3(256), 0, ctx->stream, query->d_i8, query->d_norm, \
+#define DM_LAUNCH(K, W) hipLaunchKernelGGL((distmat_i8_kernel<K, W>), grid, dim3(64 * W), 0, ctx->stream, query->d_i8, query->d_norm, \
                                         train->d_i8, train->d_norm, query->rows, query->rows_pad, train->rows, train->rows_pad, bpw, d_dist, ld, vec_ok, parity, exp_mode)
-        if (ks == 1) DM_LAUNCH(1); else if (ks == 2) DM_LAUNCH(2); else DM_LAUNCH(4);
+#ifdef SFMHIP_EXPERIMENTS
+        // eight waves (256 query rows) per train block halve the train re-reads; measured level with four on the reference's stride and
+        // 2 us slower on aligned rows (profiles/README.md, round 3): experiments builds only
+        if (nw == 8) { if (ks == 1) DM_LAUNCH(1, 8); else if (ks == 2) DM_LAUNCH(2, 8); else DM_LAUNCH(4, 8); }
+        else
+#endif
+        { if (ks == 1) DM_LAUNCH(1, 4); else if (ks == 2) DM_LAUNCH(2, 4); else DM_LAUNCH(4, 4); }
 #undef DM_LAUNCH
         SFM_HIP_TRY(ctx, hipGetLastError());
         return SFMHIP_OK;
