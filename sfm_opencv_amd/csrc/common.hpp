@@ -176,5 +176,6 @@ struct sfmhip_descset {
     int flag_slot = -1;               // d_flag = ctx->d_flagpool + flag_slot; -1: a block of its own
     // Hamming2
     uint32_t* d_u32 = nullptr;        // rows_pad x 16 words (64 B rows, zero padded)
+    uint32_t* d_f4 = nullptr;         // rows_pad x 96 words: 768 FP4 values per row (prep_hamming_fp4_kernel), nbytes <= 61 only
     int* d_flag = nullptr;
 };

@@ -121,6 +121,50 @@ __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, 
     dst[(size_t)row * 16 + 8 + k] = ((a0 >> 1) & M) | (a1 & ~M);
 }
 
+// Hamming2 on the matrix cores: every row as 768 FP4 (e2m1) values = 24 blocks of 32 = 384 bytes.  A two-bit cell (b0, b1) becomes
+// the three values (s0, s1, s0 s1), s = 1 - 2 bit -- the vertices of a regular simplex: the dot product of two cells' triples is 3
+// when the cells are equal and -1 when they differ, so   dot(row a, row b) = 4 (equal cells) - cells   and
+//     NORM_HAMMING2(a, b) = (3 cells - dot) / 4            (cells = 4 nbytes; 3 cells <= 732 values, i.e. nbytes <= 61: AKAZE's 61).
+// Value v < 3 cells: cell v / 3, plane v % 3 (any fixed order would do: both operands of the MFMA use the same one).
+// The 36 values left over carry what turns the accumulator itself into the kernel's top-2 key (knn2_hamming2_fp4_kernel):
+//   736..744 (block 23): the row's 32-row tile index (row >> 5) & 255: bit j < 7 as the value {.5, 1, 1, 1, 1, 2, 4}[j], bit 7 as 4.0 twice;
+//   732..735 (block 22) and 745..767 (block 23): 6.0 on rows past the set's end, 0 on real rows (the query side holds 6.0 there; the
+//   kernel also reads the top one of them as the pad row's block scale).
+#define H4_ROW_BYTES 384
+#define H4_MAX_NBYTES 61
+__global__ void prep_hamming_fp4_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                        uint32_t* __restrict__ dst, int rows_pad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one dword = 8 values
+    if (i >= (size_t)rows_pad * 96) return;
+    const int row = (int)(i / 96), w = (int)(i % 96);
+    const bool pad = row >= rows;
+    const int ncell3 = 12 * nbytes;
+    uint32_t out = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int v = 8 * w + n;
+        uint32_t code = 0;
+        if (v < 732) {
+            if (!pad && v < ncell3) {
+                const int cell = v / 3, plane = v - 3 * cell;
+                const uint32_t byte = src[(size_t)row * ld + (cell >> 2)];
+                const uint32_t b0 = (byte >> (2 * (cell & 3))) & 1u, b1 = (byte >> (2 * (cell & 3) + 1)) & 1u;
+                const uint32_t bit = plane == 0 ? b0 : (plane == 1 ? b1 : (b0 ^ b1));
+                code = 0x2u | (bit << 3);                    // +1.0 / -1.0
+            }
+        } else if (v >= 736 && v < 745) {
+            const int j = v - 736 < 7 ? v - 736 : 7;
+            const uint32_t bcode = j == 0 ? 1u : (j < 5 ? 2u : (j == 5 ? 4u : 6u));      // .5, 1, 1, 1, 1, 2, 4, (4, 4)
+            if ((((unsigned)row >> 5) >> j) & 1u) code = bcode;
+        } else {
+            code = pad ? 7u : 0u;                            // 6.0
+        }
+        out |= code << (4 * n);
+    }
+    dst[i] = out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-pair descriptor for the batched kernels
 // ------------------------------------------------------------------------------------------------
@@ -692,6 +736,219 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hamming2 kNN-2 on the matrix cores: v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands (rows from prep_hamming_fp4_kernel).
+// grid = (query blocks of 256, chunks, pairs [padded to 8]), block = 256: 4 waves x 64 query rows.
+//   * the wave's 64 query rows stay in registers for the whole chunk: 2 tiles x 12 K-steps x 4 dwords = 96 VGPRs, sign bits
+//     flipped (the accumulator then holds MINUS the dot product), spare values replaced by the weights below;
+//   * train rows stream through LDS by LDS-DMA, 64 rows per stage, two stages in flight.  One 1 KB instruction carries two rows
+//     (48 lanes x 16 B); the 16-byte chunks of a row are XOR-swizzled inside their group of 8 by (row >> 1) & 7, on the global
+//     side, so the 16 lanes of a ds_read_b128 group find 16 different bank slots;
+//   * every train fragment read from LDS feeds TWO MFMAs (both query tiles): 64 B/clk/CU of LDS reads at the MFMA rate;
+//   * block scales (E8M0, one per lane per instruction) make the accumulator the top-2 key itself: query blocks 0..22 carry 2^6,
+//     so acc = -64 dot; block 23 (query scale 2^2) adds the train's 8-bit tile index (weights {.5,.5,1,2,4,4,4,4,4} x the row's
+//     bit values).  Real rows: key + 192 cells = 256 distance + tile (< 2^16).  Rows past the end of a set carry 6.0 in 27 spare
+//     values that meet 6.0 on the query side, and their last K-step is scaled by 2^8 on the train side (the scale is read off the
+//     fragment itself): keys above 3e6, never selected while a real row is left.  Two VALU ops per distance (below).
+//   * chunks are power-of-two sized and aligned, <= 8192 rows, so the 8-bit tile index is monotone inside a chunk.
+// Partial output as knn2_hamming2_kernel: two keys (distance << 32 | train index) per (query row, chunk).
+// ------------------------------------------------------------------------------------------------
+typedef int   v8i  __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part, int n_pairs)
+{
+    constexpr int RB = H4_ROW_BYTES, TROWS = 64, BUF_BYTES = (TROWS / 2) * 1024, TILE_BYTES = 16 * 1024;
+    constexpr int MERGE_BYTES = 4 * 32 * 33 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES > MERGE_BYTES ? 2 * BUF_BYTES : MERGE_BYTES];
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per_pair = gridDim.x * gridDim.y, slot = lin >> 3;
+    const int pair = (slot / per_pair) * 8 + (lin & 7), rest = slot % per_pair;       // pair -> XCD, as knn2_i8_kernel
+    if (pair >= n_pairs) return;
+    const PairDesc pd = pairs[pair];
+    const int qb = rest % gridDim.x, chunk = rest / gridDim.x;
+    if (qb * 256 >= pd.nq_pad || chunk >= pd.nchunks) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    typedef const char __attribute__((address_space(1)))* gbytes;
+    typedef char __attribute__((address_space(3)))* lbytes;
+    typedef const v4i __attribute__((address_space(1)))* gv4;
+    const gbytes Q = (gbytes)(uintptr_t)pd.q;
+    const gbytes T = (gbytes)(uintptr_t)pd.t;
+    const int t_begin = chunk * pd.chunk_rows;
+    int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt_pad) t_end = pd.nt_pad;
+    const int nblocks = (t_end - t_begin) / TROWS;
+    const int q0 = qb * 256 + wave * 64;
+
+    // stationary operand
+    v4i afrag[2][12];
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            v4i a = *(gv4)(Q + (size_t)(q0 + 32 * at + l31) * RB + 16 * (2 * s + half));
+            a ^= (v4i){ (int)0x88888888, (int)0x88888888, (int)0x88888888, (int)0x88888888 };
+            if (s == 11) {
+                if (half == 0) a[3] = (a[3] & 0x0000ffff) | 0x77770000;                                  // values 732..735: 6.0
+                else a = (v4i){ 0x66664211, 0x77777776, 0x77777777, 0x77777777 };                        // tile-bit weights (9 values), then 6.0
+            }
+            asm volatile("" : "+v"(a));
+            afrag[at][s] = a;
+        }
+    const int sa_main = 133, sb = 127;                     // 2^6, 2^0
+    const int sa_last = half ? 129 : 133;                  // block 23: 2^2
+    float neg_inf = -__builtin_inff();
+    asm volatile("" : "+s"(neg_inf));                      // an SGPR operand, not a literal per instruction
+
+    float best1[2][16], best2[2][16];
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { best1[at][i] = 1.0e9f; best2[at][i] = 1.0e9f; }
+
+    // staging addresses: wave w, pass p fills row pair 4p + w of the buffer (lanes 0..47: row 2(4p+w) + lane/24, slot lane%24)
+    const int sub = lane / 24, sl = lane % 24;
+    const unsigned g_even = (unsigned)(sub * RB + 16 * ((sl & ~7) | ((sl ^ wave) & 7)));
+    const unsigned g_odd  = (unsigned)(sub * RB + 16 * ((sl & ~7) | ((sl ^ wave ^ 4) & 7)));
+    const bool stager = lane < 48;
+    auto g_stage = [&](int buf, int blk) {                 // buf: 0 / 1, wave-uniform
+        const gbytes blk_base = (gbytes)(T + (size_t)(t_begin + blk * TROWS) * RB);       // wave-uniform
+        if (stager) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                unsigned long long pb = (unsigned long long)(uintptr_t)(blk_base + (size_t)(4 * p + wave) * (2 * RB));
+                asm volatile("" : "+s"(pb));
+                __builtin_amdgcn_global_load_lds((gbytes)pb + ((p & 1) ? g_odd : g_even), (lbytes)(lds + buf * BUF_BYTES + (4 * p + wave) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // operand reads: lane (row l31 of the tile, K half): chunk 2s + half of its row, swizzled
+    int rd_off[4];
+    {
+        const int base_lane = (l31 >> 1) * 1024 + (l31 & 1) * RB, k16 = 16 * ((l31 >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rd_off[j] = base_lane + ((32 * j + 16 * half) ^ k16);
+    }
+    // One stage = two tiles of 32 trains = 24 K-steps out of the buffer rd_off[] points into, as ONE software-pipelined stream:
+    //   * train fragments are read two K-steps ahead of their MFMAs, across the tile boundary;
+    //   * the top-2 update of a finished tile (64 VALU ops per wave) is spread over K-steps 1..11 of the NEXT tile, six ops behind
+    //     each MFMA pair -- an MFMA holds the SIMD's issue port for 8 of its 32 cycles, so they cost nothing -- which needs two
+    //     accumulator sets: tile 0 of a stage fills set A while set B (tile 1 of the stage before) is consumed, and vice versa;
+    //   * two VALU ops per distance, in place: runner-up = med3(best, runner-up, key), best = med3(best, key, -inf) = min
+    //     (v_min_f32 through fminf() would canonicalise both inputs first).  asm, so that the results stay in their inputs'
+    //     registers (hipcc renamed them into a second generation of best[] and spilled the stationary operand).  hipcc pads
+    //     nothing for asm: a set is first read five MFMAs (>= 40 cycles) after its last write -- 11 wait states are required
+    //     after an 8-pass MFMA -- and the flush after the loop pads explicitly.
+    // The scheduling barriers pin this order (hipcc otherwise hoists all twelve reads of a tile, 48 registers, above the first MFMA).
+    v16f accA0, accA1, accB0, accB1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accB0[i] = 1.0e9f; accB1[i] = 1.0e9f; }
+#define H4_TOP2(B1v, B2v, KEY) asm volatile("v_med3_f32 %1, %0, %1, %2\n\tv_med3_f32 %0, %0, %2, %3" : "+v"(B1v), "+v"(B2v) : "v"(KEY), "s"(neg_inf))
+    auto top2_of = [&](v16f& p0, v16f& p1, int v) {          // value v = 0..31 of a finished tile's two accumulators
+        if (v < 16) H4_TOP2(best1[0][v], best2[0][v], p0[v]);
+        else if (v < 32) H4_TOP2(best1[1][v - 16], best2[1][v - 16], p1[v - 16]);
+    };
+    auto compute = [&]() {
+        auto rd = [&](int g) { return *(const v4i*)(lds + rd_off[(g % 12) & 3] + ((g / 12) * TILE_BYTES + 128 * ((g % 12) >> 2))); };
+        v4i bq[3];
+        bq[0] = rd(0); bq[1] = rd(1);
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            const int tile = g / 12, s = g % 12;
+            if (g + 2 < 24) bq[(g + 2) % 3] = rd(g + 2);
+            const v4i b4 = bq[g % 3];
+            const v8i b8 = { b4[0], b4[1], b4[2], b4[3], 0, 0, 0, 0 };
+            const v8i a0 = { afrag[0][s][0], afrag[0][s][1], afrag[0][s][2], afrag[0][s][3], 0, 0, 0, 0 };
+            const v8i a1 = { afrag[1][s][0], afrag[1][s][1], afrag[1][s][2], afrag[1][s][3], 0, 0, 0, 0 };
+            const int sa = s == 11 ? sa_last : sa_main;
+            v16f& c0 = tile == 0 ? accA0 : accB0;
+            v16f& c1 = tile == 0 ? accA1 : accB1;
+            v16f& p0 = tile == 0 ? accB0 : accA0;
+            v16f& p1 = tile == 0 ? accB1 : accA1;
+            int sbv = sb;
+            if (s == 11) sbv = 127 + ((b4[3] >> 27) & 8);       // rows past the end: the top value of the fragment is 6.0 (bit 30 set) -> 2^8
+            if (s == 0) {
+                v16f z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+                // the pending set is still being read: the first MFMA pair of a tile writes the OTHER set
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b8, z, 4, 4, 0, sa, 0, sb);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b8, z, 4, 4, 0, sa, 0, sb);
+            } else {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b8, c0, 4, 4, 0, sa, 0, sbv);
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b8, c1, 4, 4, 0, sa, 0, sbv);
+                top2_of(p0, p1, 3 * (s - 1)); top2_of(p0, p1, 3 * (s - 1) + 1); top2_of(p0, p1, 3 * (s - 1) + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one loop body for both buffers (the buffer is a run-time offset: an XOR on the four read addresses per stage) -- with the two
+    // buffers as separate code paths hipcc moved best[] between register sets at the joins and spilled the stationary operand
+    g_stage(0, 0);
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; ++blk) {
+        if (blk + 1 < nblocks) g_stage((blk + 1) & 1, blk + 1);
+        compute();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rd_off[j] ^= BUF_BYTES;
+        __syncthreads();
+    }
+    // flush: the last tile's accumulators (set B)
+    asm volatile("s_nop 11");
+#pragma unroll
+    for (int v = 0; v < 32; ++v) top2_of(accB0, accB1, v);
+#undef H4_TOP2
+
+    // merge across the 32 lanes that share a query row (as knn2_i8_kernel), one query tile at a time, on integer keys
+    // K = key + 192 cells = 256 distance + tile for a real train (< 2^16); a pad row or the initial value is above 2^20
+    const int off_k = 768 * pd.dim, k_pad = 1 << 20;
+    const int win_base = t_begin & ~8191;
+    int2* wk = (int2*)lds + wave * (32 * 33);
+#pragma unroll
+    for (int at = 0; at < 2; ++at) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+            wk[row * 33 + l31] = make_int2((int)best1[at][i] + off_k, (int)best2[at][i] + off_k);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int row = lane >> 1, side = lane & 1;
+        int m1 = INT_MAX, m2 = INT_MAX, i1 = 0, i2 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int l = side * 16 + j;
+            const int2 v = wk[row * 33 + l];
+            const bool c1 = v.x < m1, c2 = v.x < m2;
+            m2 = c1 ? m1 : (c2 ? v.x : m2); i2 = c1 ? i1 : (c2 ? l : i2);
+            m1 = c1 ? v.x : m1;             i1 = c1 ? l : i1;
+            const bool c3 = v.y < m2;
+            m2 = c3 ? v.y : m2;             i2 = c3 ? l : i2;
+        }
+        const int o1 = __shfl_xor(m1, 1), oi1 = __shfl_xor(i1, 1), o2 = __shfl_xor(m2, 1), oi2 = __shfl_xor(i2, 1);
+        {
+            const bool c1 = o1 < m1, c2 = o1 < m2;
+            m2 = c1 ? m1 : (c2 ? o1 : m2); i2 = c1 ? i1 : (c2 ? oi1 : i2);
+            m1 = c1 ? o1 : m1;             i1 = c1 ? oi1 : i1;
+            const bool c3 = o2 < m2;
+            m2 = c3 ? o2 : m2;             i2 = c3 ? oi2 : i2;
+        }
+        if (side == 0) {
+            const int qrow = q0 + 32 * at + row;
+            long long k1 = KEY_INVALID, k2 = KEY_INVALID;
+            if (m1 < k_pad) k1 = ((long long)(m1 >> 8) << 32) | (unsigned int)(win_base + (m1 & 255) * 32 + i1);
+            if (m2 < k_pad) k2 = ((long long)(m2 >> 8) << 32) | (unsigned int)(win_base + (m2 & 255) * 32 + i2);
+            long long* o = part + 2 * (pd.part_off + (long long)qrow * pd.nchunks + chunk);
+            o[0] = k1; o[1] = k2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge of the per-chunk partial top-2 into idx2 / dist2.
 // MODE 0: keys hold integer d^2 (int8 path): dist = sqrtf(float(d^2)); rows with 2nd d^2 >= 2^22 are
 //         appended to the rescore list (their float distances may tie where the integers do not).
@@ -912,6 +1169,13 @@ static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uin
     hipLaunchKernelGGL(prep_hamming_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_src, ld, s->rows, s->dim, (uint32_t*)s->d_u32, s->rows_pad);
     SFM_HIP_TRY(ctx, hipGetLastError());
+    if (s->dim <= H4_MAX_NBYTES) {
+        { void* q = nullptr; int rc = sfm_pool_get(ctx, (size_t)s->rows_pad * H4_ROW_BYTES, &q); if (rc) return rc; s->d_f4 = (uint32_t*)q; }
+        const size_t nw = (size_t)s->rows_pad * (H4_ROW_BYTES / 4);
+        hipLaunchKernelGGL(prep_hamming_fp4_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_src, ld, s->rows, s->dim, s->d_f4, s->rows_pad);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+    }
     return SFMHIP_OK;
 }
 
@@ -963,6 +1227,7 @@ void sfmhip_descset_destroy(sfmhip_descset* s)
     if (s->d_i8) sfm_pool_put(ctx, s->d_i8);
     if (s->d_norm) sfm_pool_put(ctx, s->d_norm);
     if (s->d_u32) sfm_pool_put(ctx, s->d_u32);
+    if (s->d_f4) sfm_pool_put(ctx, s->d_f4);
     if (s->flag_slot >= 0) ctx->flag_free.push_back(s->flag_slot);
     else if (s->d_flag) sfm_pool_put(ctx, s->d_flag);
     delete s;
@@ -1028,7 +1293,7 @@ struct KnnPlan {
     std::vector<PairDesc> pd;
     long long part_entries = 0, list_entries = 0, out_rows = 0;
     int max_qpad = 0, max_chunks = 0, max_nq = 0;
-    int path = 0;    // 1 exact f32, 2 int8 mfma, 3 hamming
+    int path = 0;    // 1 exact f32, 2 int8 mfma, 3 hamming (VALU), 4 hamming (FP4 MFMA)
     int ks = 0, dim = 0;
     bool aligned = true;
 };
@@ -1048,8 +1313,12 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
         all_exact = all_exact && q->exact_u8 && t->exact_u8;
     }
     P.dim = dim;
-    if (kind == SFMHIP_DESC_HAMMING2_U8) P.path = 3;
-    else {
+    if (kind == SFMHIP_DESC_HAMMING2_U8) {
+        // the matrix-core kernel whenever the rows fit its 768-value encoding (nbytes <= 61: AKAZE's 61-byte rows do)
+        SFM_ARG_CHECK(ctx, force_path == 0 || force_path == 3 || (force_path == 4 && dim <= H4_MAX_NBYTES));
+        P.path = (force_path == 3 || dim > H4_MAX_NBYTES) ? 3 : 4;
+    } else {
+        SFM_ARG_CHECK(ctx, force_path >= 0 && force_path <= 2);
         if (force_path == 2) { SFM_ARG_CHECK(ctx, all_exact); P.path = 2; }
         else if (force_path == 1) P.path = 1;
         else P.path = all_exact ? 2 : 1;
@@ -1057,7 +1326,7 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
     }
     // chunking: enough workgroups to fill the chip, chunks of whole 128-row blocks, <= 4096 rows (7-bit tile index)
     long long qblocks_total = 0;
-    const int qgran = (P.path == 3) ? 256 : (P.path == 1 ? 4 : 128);
+    const int qgran = (P.path >= 3) ? 256 : (P.path == 1 ? 4 : 128);
     for (int p = 0; p < n_pairs; ++p) qblocks_total += ceil_div(sets[pairs[2 * p]]->rows_pad, qgran);
     const long long target_wgs = 4LL * ctx->num_cus;
     P.pd.resize(n_pairs);
@@ -1067,15 +1336,20 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
         memset(&d, 0, sizeof d);
         d.nq = q->rows; d.nt = t->rows; d.nq_pad = q->rows_pad; d.nt_pad = t->rows_pad; d.dim = dim;
         if (P.path == 3) { d.q = q->d_u32; d.t = t->d_u32; }
+        else if (P.path == 4) { d.q = q->d_f4; d.t = t->d_f4; }
         else { d.q = q->d_i8; d.t = t->d_i8; d.qn = q->d_norm; d.tn = t->d_norm + t->rows_pad; d.qf = q->d_f32; d.tf = t->d_f32; d.ldq = q->ld; d.ldt = t->ld; }
         const int brows = (P.path == 2) ? KNN_STAGE_ROWS : 128;               // rows per staged block of the kernel that runs
-        const int tblocks = d.nt_pad / brows, max_cb = 4096 / brows;          // <= 4096 train rows per chunk (7-bit tile index)
+        const int tblocks = d.nt_pad / brows, max_cb = (P.path == 4 ? 8192 : 4096) / brows;   // <= 4096 train rows per chunk (7-bit tile index; 8 bits on path 4)
         int nch = (int)((target_wgs + qblocks_total - 1) / (qblocks_total > 0 ? qblocks_total : 1));
         if (P.path == 1) nch = 1 > nch ? 1 : (nch > 8 ? 8 : nch);
         if (nch < 1) nch = 1;
         if (nch > tblocks) nch = tblocks;
         if (nch < ceil_div(tblocks, max_cb)) nch = ceil_div(tblocks, max_cb);
-        const int cb = ceil_div(tblocks, nch);      // balanced chunks
+        int cb = ceil_div(tblocks, nch);      // balanced chunks
+        if (P.path == 4) {          // power-of-two chunks (aligned windows of <= 8192 rows: the tile index in the rows is (row >> 5) & 255)
+            int c2 = 2; while (c2 < cb && c2 * 2 * brows <= 8192) c2 *= 2;
+            cb = c2;
+        }
         nch = ceil_div(tblocks, cb);
         d.nchunks = nch; d.chunk_rows = cb * brows;
         d.part_off = P.part_entries; P.part_entries += (long long)d.nq_pad * nch;
@@ -1149,6 +1423,11 @@ static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& 
         if (P.aligned) launch_exact<true>(ctx, P, W, n_pairs, false); else launch_exact<false>(ctx, P, W, n_pairs, false);
         if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
+    } else if (P.path == 4) {
+        const dim3 grid(ceil_div(P.max_qpad, 256), P.max_chunks, round_up(n_pairs, 8));
+        hipLaunchKernelGGL(knn2_hamming2_fp4_kernel, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, n_pairs);
+        if (tev) (void)hipEventRecord(tev[1], ctx->stream);
+        hipLaunchKernelGGL(merge_kernel<2>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
     } else {
         const dim3 grid(ceil_div(P.max_qpad, 256), P.max_chunks, n_pairs);
         hipLaunchKernelGGL(knn2_hamming2_kernel, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part);

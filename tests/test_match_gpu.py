@@ -99,6 +99,59 @@ def test_knn2_hamming2(ctx, nq, nt, nb):
     _check_knn(ctx, d[0][:nq], d[1][:nt], hamming=True)
 
 
+def _knn2_hamming_dev(ctx, q, t, path):
+    import torch
+    qs = ctx.descset_hamming2(torch.from_numpy(np.ascontiguousarray(q)).cuda()); ts = ctx.descset_hamming2(torch.from_numpy(np.ascontiguousarray(t)).cuda())
+    idx = torch.empty((q.shape[0], 2), dtype=torch.int32, device="cuda"); dist = torch.empty((q.shape[0], 2), dtype=torch.float32, device="cuda")
+    ctx.knn2_dev(qs, ts, idx, dist, force_path=path)
+    ctx.synchronize()
+    return idx.cpu().numpy(), dist.cpu().numpy()
+
+
+@pytest.mark.parametrize("nq,nt,nb", [(1, 1, 61), (2, 1, 61), (3, 2, 61), (70, 33, 61), (256, 257, 61), (1000, 3000, 61), (300, 4097, 61), (257, 9000, 61),
+                                      (100, 100, 32), (500, 700, 1), (64, 5000, 17)])
+def test_knn2_hamming2_matrix_core_kernel_equals_valu_kernel_and_oracle(ctx, nq, nt, nb):
+    """Round 3: Hamming2 on the FP4 matrix cores (rows of up to 61 bytes: knn2_hamming2_fp4_kernel) against the VALU popcount kernel
+    (force_path 3) and the CPU oracle: same index pairs, same distances, on one chunk and on several (4097 / 9000 trains: windows of
+    4096), on sets smaller than one tile, on fewer than two trains (the runner-up stays missing: pad rows are never selected)."""
+    d = synth.akaze_descriptor_chain(2, max(nq, nt), nbytes=nb, seed=nq + nt)
+    q, t = d[0][:nq], d[1][:nt]
+    i4, d4 = _knn2_hamming_dev(ctx, q, t, 4)
+    i3, d3 = _knn2_hamming_dev(ctx, q, t, 3)
+    oi, od = orc.knn2_hamming2(q, t)
+    assert np.array_equal(i4, oi), f"index mismatch at rows {np.nonzero((i4 != oi).any(1))[0][:10]}"
+    assert np.array_equal(d4.view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(i3, oi) and np.array_equal(d3.view(np.uint32), od.view(np.uint32))
+
+
+def test_knn2_hamming2_matrix_core_kernel_ties_and_extremes(ctx):
+    """Ties go to the lower train index across lanes, tiles, stages and chunks (rows repeated all over a 5000-row set); distance 0
+    (identical rows) and the maximum 244 (complement of every cell) both come out exactly."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (7, 61), dtype=np.uint8)
+    t = base[rng.integers(0, 7, 5000)]
+    q = np.concatenate([base, base ^ np.uint8(0x55), base ^ np.uint8(0xFF), rng.integers(0, 256, (300, 61), dtype=np.uint8)])
+    i4, d4 = _knn2_hamming_dev(ctx, q, t, 4)
+    oi, od = orc.knn2_hamming2(q, t)
+    assert np.array_equal(i4, oi) and np.array_equal(d4.view(np.uint32), od.view(np.uint32))
+    assert d4[:7, 0].max() == 0.0
+    allq = np.array([[0x00] * 61, [0xFF] * 61], np.uint8); allt = np.array([[0x55] * 61, [0x00] * 61, [0xAA] * 61], np.uint8)
+    i4, d4 = _knn2_hamming_dev(ctx, allq, allt, 4)
+    oi, od = orc.knn2_hamming2(allq, allt)
+    assert np.array_equal(i4, oi) and np.array_equal(d4, od) and d4.max() == 244.0
+
+
+def test_knn2_hamming2_forced_paths_are_checked(ctx):
+    import torch
+    t64 = ctx.descset_hamming2(torch.zeros((10, 64), dtype=torch.uint8, device="cuda"))
+    idx = torch.empty((10, 2), dtype=torch.int32, device="cuda"); dist = torch.empty((10, 2), dtype=torch.float32, device="cuda")
+    with pytest.raises(api.SfmHipError):
+        ctx.knn2_dev(t64, t64, idx, dist, force_path=4)         # 64-byte rows do not fit the 768-value encoding
+    ctx.knn2_dev(t64, t64, idx, dist, force_path=0)             # ... and go to the VALU kernel by themselves
+    ctx.synchronize()
+    assert idx.cpu().numpy()[:, 0].tolist() == [0] * 10
+
+
 def test_match_features_l2_and_chain(ctx):
     descs = synth.sift_descriptor_chain(4, 700, seed=21)
     got = api.match_features_for_all(descs, ctx=ctx)
