@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s measured copy
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA = 2x bf16 dense (~2.5 PFLOP/s)
+FP4_MFMA_PEAK_TFLOPS = 10000.0  # dense FP4 MFMA (block-scaled v_mfma_scale_f32_32x32x64_f8f6f4), ~10 PFLOP/s
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6: 256 CUs x 4 SIMD-32 x 2.4 GHz, one 32-bit lane-op per lane and cycle (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 # TCC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from separate rocprofv3 --pmc passes over this command at
 # N=1 / C4: recorded figures, NOT measured in the run that prints them (counters are not collectable in-process)
@@ -46,7 +47,7 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6: 256 CUs x 4 SIMD-3
 SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissection (the longest solver launch)
 RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (3.045e8, "profiles/r03_traffic_pmc.md"),
                     "distmat_i8_kernel<4>": (4.881e8, "profiles/r03_traffic_pmc.md"),
-                    "knn2_hamming2_kernel": (6.368e8, "profiles/r03_traffic_pmc.md"),
+                    "knn2_hamming2_kernel": (6.368e8, "profiles/r03_traffic_pmc.md"),     # the VALU kernel (62..64-byte rows), not on the bench path any more
                     "ba_camschur_kernel": (9.94e7, "profiles/r03_traffic_pmc.md")}      # 2 x FETCH_SIZE (streaming reads; raw for gathers / scalar loads) + WRITE_SIZE
 
 
@@ -520,19 +521,20 @@ def main():
                                 "4.2 POP/s, experiments/mfma_i8_bench.hip)"}
         roof_ham = ham_out = None
         if ham is not None and ham["calls"]:
-            # knn2_hamming2_kernel: per (query row, train row) 8 x [v_xor, v_bitop3 (xor + or), v_bcnt accumulate] = 24 32-bit lane
-            # operations for the 256 two-bit cells of a 64-byte row (+ 5 for the key and the running top-2, not counted)
-            lane_ops = 24.0 * n_desc * n_desc * n_pairs_l
+            # knn2_hamming2_fp4_kernel (round 3): every two-bit cell as the simplex triple (s0, s1, s0 s1) in FP4, the distance out of
+            # the dot product of two rows' 3 x 244 = 732 values (padded to 768 = 12 K-steps of v_mfma_scale_f32_32x32x64_f8f6f4).
+            # Priced on the 732 useful multiply-adds per row pair against the dense FP4 MFMA peak.
+            flops = 2.0 * 732 * n_desc * n_desc * n_pairs_l
             ham_net = max(ham["kernel_ms"] - ev_overhead_ms, 1e-9)
-            roof_ham = {"kernel": "knn2_hamming2_kernel", "bound": "valu_int", "achieved": lane_ops / (ham_net * 1e-3) / 1e12,
-                        "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": lane_ops / (ham_net * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
-                        "algorithmic_ops": lane_ops, "avg_launch_ms": ham["kernel_ms"], "event_bracket_overhead_ms": ev_overhead_ms,
+            roof_ham = {"kernel": "knn2_hamming2_fp4_kernel", "bound": "mfma", "achieved": flops / (ham_net * 1e-3) / 1e12,
+                        "peak": FP4_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (ham_net * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS,
+                        "algorithmic_ops": flops, "avg_launch_ms": ham["kernel_ms"], "event_bracket_overhead_ms": ev_overhead_ms,
                         "avg_launch_ms_net": ham_net, "launches_timed": int(ham["calls"]), "merge_ms": ham["merge_ms"],
-                        "traffic": RECORDED_TRAFFIC["knn2_hamming2_kernel"][0] if (world == 1 and args.config == "C4") else None,
-                        "traffic_source": (RECORDED_TRAFFIC["knn2_hamming2_kernel"][1] + " (recorded by separate --pmc passes, not measured in this run)") if (world == 1 and args.config == "C4") else None,
-                        "measured_issue_rate": "every VALU mix measured on this part sustains ~1.9 ns per instruction and SIMD (profiles/r03_valu_issue_rates.log): 28 instructions x 64 rows per wave put this kernel AT that rate; `peak` is the guide's 2-cycle figure",
-                        "note": "one launch = all chain pairs of this rank; integer VALU work (xor / or / popcount), no matrix-core formulation "
-                                "of a two-bit-cell Hamming distance is exact; bytes are negligible (64 B per row)"}
+                        "traffic": None,
+                        "issued": "12 K-steps x 2 MFMAs of 32 cycles per (64 queries x 32 trains) on padded 5120-row sets: 1.91e6 matrix-pipe cycles per SIMD and launch "
+                                  "(SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_hamming_fp4_pmc.md) = 0.80 ms at 2.4 GHz",
+                        "note": "one launch = all chain pairs of this rank; the VALU popcount kernel of rounds 1-2 (knn2_hamming2_kernel, 3.33 ms, still used "
+                                "for 62..64-byte rows) ran at the VALU issue rate; peak = dense FP4 MFMA (MI355X_MICROARCH.md)"}
             ham_out = {"value": (n_img_match - 1) * m_steps / ham["t"], "ms_per_pass": 1e3 * ham["t"] / m_steps, "pairs": n_img_match - 1,
                        "passes_timed": m_steps, "matches_rank0": ham["matches"], "descriptor": "61-byte rows (AKAZE M-LDB shape), NORM_HAMMING2",
                        "cpu_baseline": ham.get("cpu"),

@@ -131,6 +131,9 @@ __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, 
 //   732..735 (block 22) and 745..767 (block 23): 6.0 on rows past the set's end, 0 on real rows (the query side holds 6.0 there; the
 //   kernel also reads the top one of them as the pad row's block scale).
 #define H4_ROW_BYTES 384
+#ifndef H4_WAVES
+#define H4_WAVES 8             // waves per workgroup of knn2_hamming2_fp4_kernel (4 or 8)
+#endif
 #define H4_MAX_NBYTES 61
 __global__ void prep_hamming_fp4_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
                                         uint32_t* __restrict__ dst, int rows_pad)
@@ -737,12 +740,14 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
 
 // ------------------------------------------------------------------------------------------------
 // Hamming2 kNN-2 on the matrix cores: v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands (rows from prep_hamming_fp4_kernel).
-// grid = (query blocks of 256, chunks, pairs [padded to 8]), block = 256: 4 waves x 64 query rows.
+// grid = (query blocks of 64 NW rows, chunks, pairs [padded to 8]), block = NW waves x 64 query rows; NW = 8 (512 rows, one workgroup
+// per CU) is what runs: a staged train row then serves 512 queries, and every wave issues 3 LDS-DMA pieces per stage instead of 6
+// -- the issue cost of those pieces was 22 % of the 4-wave kernel (experiments: H4_EXP).
 //   * the wave's 64 query rows stay in registers for the whole chunk: 2 tiles x 12 K-steps x 4 dwords = 96 VGPRs, sign bits
 //     flipped (the accumulator then holds MINUS the dot product), spare values replaced by the weights below;
-//   * train rows stream through LDS by LDS-DMA, 64 rows per stage, two stages in flight.  One 1 KB instruction carries two rows
-//     (48 lanes x 16 B); the 16-byte chunks of a row are XOR-swizzled inside their group of 8 by (row >> 1) & 7, on the global
-//     side, so the 16 lanes of a ds_read_b128 group find 16 different bank slots;
+//   * train rows stream through LDS by LDS-DMA, 64 rows (24 KB, back to back) per stage, two stages in flight; the 16-byte chunks of
+//     a row are XOR-swizzled inside their group of 8 by (row >> 1) & 7, on the global side, so the 16 lanes of a ds_read_b128 group
+//     (16 rows, 384 B apart) find 16 different bank slots;
 //   * every train fragment read from LDS feeds TWO MFMAs (both query tiles): 64 B/clk/CU of LDS reads at the MFMA rate;
 //   * block scales (E8M0, one per lane per instruction) make the accumulator the top-2 key itself: query blocks 0..22 carry 2^6,
 //     so acc = -64 dot; block 23 (query scale 2^2) adds the train's 8-bit tile index (weights {.5,.5,1,2,4,4,4,4,4} x the row's
@@ -755,18 +760,31 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
 typedef int   v8i  __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part, int n_pairs)
+template <int NW>        // waves per workgroup (4 or 8), 64 query rows each
+__global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const PairDesc* __restrict__ pairs, long long* __restrict__ part, int n_pairs)
 {
-    constexpr int RB = H4_ROW_BYTES, TROWS = 64, BUF_BYTES = (TROWS / 2) * 1024, TILE_BYTES = 16 * 1024;
-    constexpr int MERGE_BYTES = 4 * 32 * 33 * 8;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES > MERGE_BYTES ? 2 * BUF_BYTES : MERGE_BYTES];
+#ifdef __HIP_DEVICE_COMPILE__      // the host pass only needs the launch stub: instantiating a TEMPLATE body with gfx950 builtins there drops the stub
+#ifndef H4_TROWS
+#define H4_TROWS 64
+#endif
+    constexpr int RB = H4_ROW_BYTES, TROWS = H4_TROWS, BUF_BYTES = TROWS * RB, BUF_STRIDE = TROWS * 512, TILE_BYTES = 32 * RB, QB = 64 * NW;
+    constexpr int NG = 12 * (TROWS / 32);                    // K-steps per stage
+#if !defined(H4_EXP) || !defined(SFMHIP_EXPERIMENTS)
+#undef H4_EXP
+#define H4_EXP 0               // timing experiments only (SFMHIP_EXPERIMENTS builds; wrong results): 1 = no staging after the first stage, 2 = no barriers, 4 = no top-2 updates, 8 = no fragment reads after the first three
+#endif
+
+    constexpr int PASSES = BUF_BYTES / (1024 * NW);          // LDS-DMA instructions per wave and stage: 6 (4 waves) / 3 (8 waves)
+    constexpr int MERGE_BYTES = NW * 32 * 33 * 8, STAGE_BYTES = BUF_STRIDE + BUF_BYTES;
+    static_assert(BUF_BYTES % (1024 * NW) == 0 && BUF_BYTES <= BUF_STRIDE, "whole 1 KB pieces per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int per_pair = gridDim.x * gridDim.y, slot = lin >> 3;
     const int pair = (slot / per_pair) * 8 + (lin & 7), rest = slot % per_pair;       // pair -> XCD, as knn2_i8_kernel
     if (pair >= n_pairs) return;
     const PairDesc pd = pairs[pair];
     const int qb = rest % gridDim.x, chunk = rest / gridDim.x;
-    if (qb * 256 >= pd.nq_pad || chunk >= pd.nchunks) return;
+    if (qb * QB >= pd.nq_pad || chunk >= pd.nchunks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -778,7 +796,11 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
     const int t_begin = chunk * pd.chunk_rows;
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt_pad) t_end = pd.nt_pad;
     const int nblocks = (t_end - t_begin) / TROWS;
-    const int q0 = qb * 256 + wave * 64;
+    const int q0 = qb * QB + wave * 64;
+    // sets are padded to 256 rows: with 512-row query blocks the upper waves of the last block may have no rows; they still stage and
+    // meet the barriers, on the block's first rows, and write nothing
+    const bool has_rows = q0 < pd.nq_pad;
+    const int q0r = has_rows ? q0 : qb * QB;
 
     // stationary operand
     v4i afrag[2][12];
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
     for (int at = 0; at < 2; ++at)
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
-            v4i a = *(gv4)(Q + (size_t)(q0 + 32 * at + l31) * RB + 16 * (2 * s + half));
+            v4i a = *(gv4)(Q + (size_t)(q0r + 32 * at + l31) * RB + 16 * (2 * s + half));
             a ^= (v4i){ (int)0x88888888, (int)0x88888888, (int)0x88888888, (int)0x88888888 };
             if (s == 11) {
                 if (half == 0) a[3] = (a[3] & 0x0000ffff) | 0x77770000;                                  // values 732..735: 6.0
@@ -795,8 +817,11 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
             asm volatile("" : "+v"(a));
             afrag[at][s] = a;
         }
-    const int sa_main = 133, sb = 127;                     // 2^6, 2^0
-    const int sa_last = half ? 129 : 133;                  // block 23: 2^2
+    // block scales, one register each: query side 2^6 on the even blocks (lanes 0..31) and 2^2 on the odd ones (lanes 32..63), train
+    // side 2^0 / 2^4 -- so every data block is scaled by 2^6 -- except in the last K-step, where the train side is 2^0 on both (block 23
+    // = 2^2) or 2^8 on a pad row
+    const int sa = half ? 129 : 133;
+    const int sb = half ? 131 : 127;
     float neg_inf = -__builtin_inff();
     asm volatile("" : "+s"(neg_inf));                      // an SGPR operand, not a literal per instruction
 
@@ -806,26 +831,31 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
 #pragma unroll
         for (int i = 0; i < 16; ++i) { best1[at][i] = 1.0e9f; best2[at][i] = 1.0e9f; }
 
-    // staging addresses: wave w, pass p fills row pair 4p + w of the buffer (lanes 0..47: row 2(4p+w) + lane/24, slot lane%24)
-    const int sub = lane / 24, sl = lane % 24;
-    const unsigned g_even = (unsigned)(sub * RB + 16 * ((sl & ~7) | ((sl ^ wave) & 7)));
-    const unsigned g_odd  = (unsigned)(sub * RB + 16 * ((sl & ~7) | ((sl ^ wave ^ 4) & 7)));
-    const bool stager = lane < 48;
+    // staging: the buffer is the stage's 64 rows back to back (24 KB); piece NW p + w (1 KB, one LDS-DMA instruction of wave w) covers
+    // LDS bytes [1024 (NW p + w), +1024): the lane's 16 bytes are slot (pos % 384) / 16 of row pos / 384, which holds chunk
+    // slot ^ ((row >> 1) & 7) (inside its group of 8) of that row.
+    // Per-lane source offsets: three registers at most (4 waves: pieces 12 apart are 32 rows apart and repeat the pattern).  The
+    // kernel sits close to the 256-register limit, and ONE spilled fragment once made the loop wait for its reload with
+    // s_waitcnt vmcnt(0) -- i.e. for the LDS-DMA pieces just issued, every stage: 22 % of the kernel.
+    unsigned g_off[PASSES < 3 ? PASSES : 3];
+#pragma unroll
+    for (int p = 0; p < (PASSES < 3 ? PASSES : 3); ++p) {
+        const int pos = (NW * p + wave) * 1024 + lane * 16, r = pos / RB, sl = (pos % RB) / 16;
+        g_off[p] = (unsigned)(r * RB + 16 * ((sl & ~7) | ((sl ^ (r >> 1)) & 7)));
+    }
     auto g_stage = [&](int buf, int blk) {                 // buf: 0 / 1, wave-uniform
         const gbytes blk_base = (gbytes)(T + (size_t)(t_begin + blk * TROWS) * RB);       // wave-uniform
-        if (stager) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                unsigned long long pb = (unsigned long long)(uintptr_t)(blk_base + (size_t)(4 * p + wave) * (2 * RB));
-                asm volatile("" : "+s"(pb));
-                __builtin_amdgcn_global_load_lds((gbytes)pb + ((p & 1) ? g_odd : g_even), (lbytes)(lds + buf * BUF_BYTES + (4 * p + wave) * 1024), 16, 0, 0);
-            }
+        for (int p = 0; p < PASSES; ++p) {
+            unsigned long long pb = (unsigned long long)(uintptr_t)(blk_base + (p / 3) * (8 * NW * RB));      // three pieces per wave = 8 NW rows
+            asm volatile("" : "+s"(pb));
+            __builtin_amdgcn_global_load_lds((gbytes)pb + g_off[p % 3], (lbytes)(lds + buf * BUF_STRIDE + (NW * p + wave) * 1024), 16, 0, 0);
         }
     };
     // operand reads: lane (row l31 of the tile, K half): chunk 2s + half of its row, swizzled
     int rd_off[4];
     {
-        const int base_lane = (l31 >> 1) * 1024 + (l31 & 1) * RB, k16 = 16 * ((l31 >> 1) & 7);
+        const int base_lane = l31 * RB, k16 = 16 * ((l31 >> 1) & 7);
 #pragma unroll
         for (int j = 0; j < 4; ++j) rd_off[j] = base_lane + ((32 * j + 16 * half) ^ k16);
     }
@@ -853,14 +883,13 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
         v4i bq[3];
         bq[0] = rd(0); bq[1] = rd(1);
 #pragma unroll
-        for (int g = 0; g < 24; ++g) {
-            const int tile = g / 12, s = g % 12;
-            if (g + 2 < 24) bq[(g + 2) % 3] = rd(g + 2);
+        for (int g = 0; g < NG; ++g) {
+            const int tile = (g / 12) & 1, s = g % 12;     // accumulator set by tile parity
+            if (g + 2 < NG && !((H4_EXP & 8) && g >= 1)) bq[(g + 2) % 3] = rd(g + 2);
             const v4i b4 = bq[g % 3];
             const v8i b8 = { b4[0], b4[1], b4[2], b4[3], 0, 0, 0, 0 };
             const v8i a0 = { afrag[0][s][0], afrag[0][s][1], afrag[0][s][2], afrag[0][s][3], 0, 0, 0, 0 };
             const v8i a1 = { afrag[1][s][0], afrag[1][s][1], afrag[1][s][2], afrag[1][s][3], 0, 0, 0, 0 };
-            const int sa = s == 11 ? sa_last : sa_main;
             v16f& c0 = tile == 0 ? accA0 : accB0;
             v16f& c1 = tile == 0 ? accA1 : accB1;
             v16f& p0 = tile == 0 ? accB0 : accA0;
@@ -877,8 +906,11 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
             } else {
                 c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b8, c0, 4, 4, 0, sa, 0, sbv);
                 c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b8, c1, 4, 4, 0, sa, 0, sbv);
-                top2_of(p0, p1, 3 * (s - 1)); top2_of(p0, p1, 3 * (s - 1) + 1); top2_of(p0, p1, 3 * (s - 1) + 2);
+                if (!(H4_EXP & 4)) { top2_of(p0, p1, 3 * (s - 1)); top2_of(p0, p1, 3 * (s - 1) + 1); top2_of(p0, p1, 3 * (s - 1) + 2); }
             }
+            // pin the pair here: set B's second chain has no reader before the next trip of the loop, and LLVM sank all twelve of
+            // its MFMAs (and their twelve train fragments: 48 registers) below the stage's last step
+            asm volatile("" : "+v"(c0), "+v"(c1));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -887,12 +919,13 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
     g_stage(0, 0);
     __syncthreads();
     for (int blk = 0; blk < nblocks; ++blk) {
-        if (blk + 1 < nblocks) g_stage((blk + 1) & 1, blk + 1);
+        if (blk + 1 < nblocks && !(H4_EXP & 1)) g_stage((blk + 1) & 1, blk + 1);
         compute();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rd_off[j] ^= BUF_BYTES;
-        __syncthreads();
+        for (int j = 0; j < 4; ++j) rd_off[j] ^= BUF_STRIDE;
+        if (!(H4_EXP & 2)) __syncthreads();
     }
+    if (H4_EXP & 2) __syncthreads();
     // flush: the last tile's accumulators (set B)
     asm volatile("s_nop 11");
 #pragma unroll
@@ -934,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
             const bool c3 = o2 < m2;
             m2 = c3 ? o2 : m2;             i2 = c3 ? oi2 : i2;
         }
-        if (side == 0) {
+        if (side == 0 && has_rows) {
             const int qrow = q0 + 32 * at + row;
             long long k1 = KEY_INVALID, k2 = KEY_INVALID;
             if (m1 < k_pad) k1 = ((long long)(m1 >> 8) << 32) | (unsigned int)(win_base + (m1 & 255) * 32 + i1);
@@ -946,6 +979,7 @@ __global__ __launch_bounds__(256, 2) void knn2_hamming2_fp4_kernel(const PairDes
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1326,7 +1360,7 @@ static int plan_pairs(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n_sets, 
     }
     // chunking: enough workgroups to fill the chip, chunks of whole 128-row blocks, <= 4096 rows (7-bit tile index)
     long long qblocks_total = 0;
-    const int qgran = (P.path >= 3) ? 256 : (P.path == 1 ? 4 : 128);
+    const int qgran = (P.path == 4) ? 64 * H4_WAVES : (P.path == 3 ? 256 : (P.path == 1 ? 4 : 128));
     for (int p = 0; p < n_pairs; ++p) qblocks_total += ceil_div(sets[pairs[2 * p]]->rows_pad, qgran);
     const long long target_wgs = 4LL * ctx->num_cus;
     P.pd.resize(n_pairs);
@@ -1424,8 +1458,8 @@ static int knn2_pairs_enqueue(sfmhip_ctx* ctx, const KnnPlan& P, const KnnWork& 
         if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<1>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
     } else if (P.path == 4) {
-        const dim3 grid(ceil_div(P.max_qpad, 256), P.max_chunks, round_up(n_pairs, 8));
-        hipLaunchKernelGGL(knn2_hamming2_fp4_kernel, grid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, n_pairs);
+        const dim3 grid(ceil_div(P.max_qpad, 64 * H4_WAVES), P.max_chunks, round_up(n_pairs, 8));
+        hipLaunchKernelGGL(knn2_hamming2_fp4_kernel<H4_WAVES>, grid, dim3(64 * H4_WAVES), 0, ctx->stream, W.d_pd, W.d_part, n_pairs);
         if (tev) (void)hipEventRecord(tev[1], ctx->stream);
         hipLaunchKernelGGL(merge_kernel<2>, mgrid, dim3(256), 0, ctx->stream, W.d_pd, W.d_part, d_idx2, d_dist2, (int*)nullptr, W.d_count, 0);
     } else {
