@@ -80,6 +80,8 @@ const char* sfmhip_version(void);
  * L2: a device pass checks whether every value is an integer in [0,255] (OpenCV SIFT output is);
  *     if so the set also carries a biased int8 copy + squared norms and is matched on the int8
  *     MFMA path, which is exact; otherwise only the exact fp32 direct-difference path is used.
+ * Hamming2 (nbytes <= 64): rows re-encoded for the popcount kernel (64 B per row) and, for nbytes <= 61 (AKAZE: 61), as 768 FP4
+ *     values (384 B per row) for the matrix-core kernel: NORM_HAMMING2 out of a dot product, exactly (csrc/match.hip).
  * host variants copy the rows to HBM first. */
 int sfmhip_descset_create_l2_host(sfmhip_ctx*, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out);
 int sfmhip_descset_create_l2_dev (sfmhip_ctx*, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out);
@@ -97,7 +99,8 @@ int sfmhip_descset_info(sfmhip_descset*, int* kind, int* rows, int* dim, int* ex
  * distance, ties -> lower train index, missing neighbours idx=-1 / dist=FLT_MAX or INT_MAX).
  * idx2: rows_q x 2 int32.  dist2: rows_q x 2 float (L2: sqrtf of the squared distance;
  * Hamming2: the integer distance converted to float, as BFMatcher::knnMatchImpl does).
- * force_path: 0 = auto, 1 = exact fp32 direct-difference path, 2 = int8 MFMA path (E_ARG if unusable). */
+ * force_path: 0 = auto; L2 sets: 1 = exact fp32 direct-difference path, 2 = int8 MFMA path (E_ARG if unusable); Hamming2 sets: 3 = the
+ * VALU popcount kernel, 4 = the FP4 matrix-core kernel (rows of <= 61 bytes; E_ARG otherwise).  Auto takes 4 whenever the rows fit. */
 int sfmhip_knn2_dev(sfmhip_ctx*, const sfmhip_descset* query, const sfmhip_descset* train,
                     int32_t* d_idx2, float* d_dist2, int force_path);
 
