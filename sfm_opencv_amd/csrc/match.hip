@@ -310,6 +310,9 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bf[ks], acc, 0, 0, 0);
             // C[row = query (reg), col = train (lane&31)].  key = (|b|^2 - 2 a.b) * 128 + local tile index.
             // Three VALU ops per accumulator: v_lshl_add_u32, v_med3_i32 (second smallest of {best1 <= best2, key}), v_min_i32.
+            // (Round 3 tried compare-and-skip -- a key only matters below the runner-up, ~2 / j of the time for the j-th train: key +
+            // v_cmp + s_cbranch_vccnz to an out-of-line update per register, 2.2 instructions per distance -- and measured 1.20 ms
+            // against 0.87: sixteen dependent compare -> branch waits per tile cost more than the sixteen instructions saved.)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = (int)(((unsigned)acc[i] << 8) + (unsigned)nbt);
