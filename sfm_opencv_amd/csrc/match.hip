@@ -77,22 +77,70 @@ __device__ __forceinline__ void prep_l2_rows(const float* __restrict__ src, size
     if (bad) atomicOr(flag, 1);
 }
 
-__global__ void prep_l2_kernel(const float* __restrict__ src, size_t ld, int rows, int dim, int dim_pad,
-                               int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int rows_pad)
+// The same for rows whose length is a multiple of 16 floats and whose int8 copy has no padding columns (SIFT: 128), 16 values per
+// lane: four 16-byte loads, v_cvt_pk_u8_f32 (convert + clamp) and a convert-back compare per value for the exactness verdict, the
+// bias as one XOR per dword, the two sums as v_dot4_i32_i8, one 16-byte store -- a third of the VALU work per byte of prep_l2_rows,
+// which sat at the issue rate rather than at the memory rate.  (For values that are not integers in [0, 255] the int8 row differs
+// from prep_l2_rows' -- and is never read: the set is flagged inexact.)
+__device__ __forceinline__ void prep_l2_rows16(const float* __restrict__ src, size_t ld, int rows, int dim, int rows_pad,
+                                               int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int wave_index)
 {
-    prep_l2_rows(src, ld, rows, dim, dim_pad, rows_pad, dst, norm, flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int lpr = dim >> 4;                           // lanes per row: 2, 4 or 8
+    const int row = wave_index * (64 / lpr) + lane / lpr, k = (lane % lpr) * 16;
+    if (row >= rows_pad) return;
+    int acc = 0, sum = 0, bad = 0;
+    v4i packed = { 0, 0, 0, 0 };
+    if (row < rows) {
+        const float4* rp = (const float4*)(src + (size_t)row * ld + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = rp[j];
+            unsigned u = __builtin_amdgcn_cvt_pk_u8_f32(t.x, 0, 0);
+            u = __builtin_amdgcn_cvt_pk_u8_f32(t.y, 1, u);
+            u = __builtin_amdgcn_cvt_pk_u8_f32(t.z, 2, u);
+            u = __builtin_amdgcn_cvt_pk_u8_f32(t.w, 3, u);
+            bad |= ((float)(u & 255u) != t.x) | ((float)((u >> 8) & 255u) != t.y) | ((float)((u >> 16) & 255u) != t.z) | ((float)(u >> 24) != t.w);
+            const int q = (int)(u ^ 0x80808080u);       // value - 128 in every byte
+            packed[j] = q;
+            acc = __builtin_amdgcn_sdot4(q, q, acc, false);
+            sum = __builtin_amdgcn_sdot4(q, 0x01010101, sum, false);
+        }
+    }
+    *(v4i*)(dst + (size_t)row * dim + k) = packed;
+    for (int off = lpr >> 1; off > 0; off >>= 1) { acc += __shfl_xor(acc, off); sum += __shfl_xor(sum, off); }
+    if (lane % lpr == 0) {
+        norm[row] = row < rows ? acc : PAD_NORM;
+        norm[rows_pad + row] = row < rows ? acc + 2 * sum : PAD_NORM;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+// host side of the choice (per launch: every image of a batch must qualify)
+static inline bool prep_l2_fast(const float* src, size_t ld, int dim, int dim_pad)
+{
+    return dim == dim_pad && (dim % 16) == 0 && dim >= 32 && (ld % 4) == 0 && (((uintptr_t)src) % 16) == 0;
+}
+
+__global__ void prep_l2_kernel(const float* __restrict__ src, size_t ld, int rows, int dim, int dim_pad,
+                               int8_t* __restrict__ dst, int32_t* __restrict__ norm, int* __restrict__ flag, int rows_pad, int fast)
+{
+    const int wave_index = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (fast) prep_l2_rows16(src, ld, rows, dim, rows_pad, dst, norm, flag, wave_index);
+    else prep_l2_rows(src, ld, rows, dim, dim_pad, rows_pad, dst, norm, flag, wave_index);
 }
 
 // batched form: one launch prepares many images (blockIdx.y = image)
 struct PrepDesc { const float* src; size_t ld; int rows, dim, dim_pad, rows_pad; int8_t* dst; int32_t* norm; int* flag; };
-__global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl)
+__global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl, int fast)
 {
     const PrepDesc d = tbl[blockIdx.y];
     // table pointers are generic to the compiler; round-trip through the global address space so the loads/stores are global_*
     const float* src = (const float*)(const float __attribute__((address_space(1)))*)(uintptr_t)d.src;
     int8_t* dst = (int8_t*)(int8_t __attribute__((address_space(1)))*)(uintptr_t)d.dst;
     int32_t* norm = (int32_t*)(int32_t __attribute__((address_space(1)))*)(uintptr_t)d.norm;
-    prep_l2_rows(src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, dst, norm, d.flag, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int wave_index = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (fast) prep_l2_rows16(src, d.ld, d.rows, d.dim, d.rows_pad, dst, norm, d.flag, wave_index);
+    else prep_l2_rows(src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, dst, norm, d.flag, wave_index);
 }
 
 // Hamming2: rows into 64-byte zero-padded rows, re-encoded so that one dword carries 32 two-bit cells' LOW bits and
@@ -1150,8 +1198,10 @@ static int descset_prepare_l2(sfmhip_ctx* ctx, sfmhip_descset* s)
     rc = descset_flag_slot(ctx, s); if (rc) return rc;
     SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
     const int waves_per_block = 4;
-    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block * (256 / s->dim_pad))), dim3(64 * waves_per_block), 0, ctx->stream,
-                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
+    const bool fast = prep_l2_fast(s->d_f32, s->ld, s->dim, s->dim_pad);
+    const int rows_per_wave = fast ? 1024 / s->dim : 256 / s->dim_pad;
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, waves_per_block * rows_per_wave)), dim3(64 * waves_per_block), 0, ctx->stream,
+                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad, fast ? 1 : 0);
     SFM_HIP_TRY(ctx, hipGetLastError());
     s->exact_pending = true;
     return SFMHIP_OK;
@@ -1278,8 +1328,9 @@ int sfmhip_descset_refresh(sfmhip_descset* s)
     sfmhip_ctx* ctx = s->ctx;
     if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) return SFMHIP_OK;
     SFM_HIP_TRY(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, 4 * (256 / s->dim_pad))), dim3(256), 0, ctx->stream,
-                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad);
+    const bool fast = prep_l2_fast(s->d_f32, s->ld, s->dim, s->dim_pad);
+    hipLaunchKernelGGL(prep_l2_kernel, dim3(ceil_div(s->rows_pad, 4 * (fast ? 1024 / s->dim : 256 / s->dim_pad))), dim3(256), 0, ctx->stream,
+                       s->d_f32, s->ld, s->rows, s->dim, s->dim_pad, s->d_i8, s->d_norm, s->d_flag, s->rows_pad, fast ? 1 : 0);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
 }
@@ -1291,11 +1342,13 @@ int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
     SFM_RANGE("sfmhip_descsets_refresh");
     SFM_ARG_CHECK(ctx, ctx && (sets || n == 0) && n >= 0);
     std::vector<PrepDesc> tbl;
-    int max_pad = 0;
+    int max_pad = 0, rows_per_block = 1 << 30;
+    bool fast = true;
     for (int i = 0; i < n; ++i) {
         const sfmhip_descset* s = sets[i];
         SFM_ARG_CHECK(ctx, s != nullptr);
         if (s->kind != SFMHIP_DESC_L2_F32 || !s->d_i8) continue;
+        fast = fast && prep_l2_fast(s->d_f32, s->ld, s->dim, s->dim_pad);
         PrepDesc d; d.src = s->d_f32; d.ld = s->ld; d.rows = s->rows; d.dim = s->dim; d.dim_pad = s->dim_pad; d.rows_pad = s->rows_pad;
         d.dst = s->d_i8; d.norm = s->d_norm; d.flag = s->d_flag;
         tbl.push_back(d);
@@ -1305,7 +1358,9 @@ int sfmhip_descsets_refresh(sfmhip_ctx* ctx, sfmhip_descset* const* sets, int n)
     void* d_tbl = nullptr;
     int rc = sfm_scratch2(ctx, tbl.size() * sizeof(PrepDesc), &d_tbl); if (rc) return rc;
     SFM_HIP_TRY(ctx, hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * sizeof(PrepDesc), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(prep_l2_batched_kernel, dim3(ceil_div(max_pad, 8), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepDesc*)d_tbl);   // >= 2 rows per wave
+    // rows per 4-wave block: the smallest over the batch (16 values per lane when every image qualifies, else 4: >= 2 rows per wave)
+    for (const PrepDesc& d : tbl) { const int r = 4 * (fast ? 1024 / d.dim : 256 / d.dim_pad); if (r < rows_per_block) rows_per_block = r; }
+    hipLaunchKernelGGL(prep_l2_batched_kernel, dim3(ceil_div(max_pad, rows_per_block), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepDesc*)d_tbl, fast ? 1 : 0);
     SFM_HIP_TRY(ctx, hipGetLastError());
     return SFMHIP_OK;
 }
