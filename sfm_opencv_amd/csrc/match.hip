@@ -911,7 +911,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
         for (int j = 0; j < 4; ++j) rd_off[j] = base_lane + ((32 * j + 16 * half) ^ k16);
     }
     // One stage = two tiles of 32 trains = 24 K-steps out of the buffer rd_off[] points into, as ONE software-pipelined stream:
-    //   * train fragments are read two K-steps ahead of their MFMAs, across the tile boundary;
+    //   * train fragments are read H4_AHEAD K-steps ahead of their MFMAs, across the tile boundary;
     //   * the top-2 update of a finished tile (64 VALU ops per wave) is spread over K-steps 1..11 of the NEXT tile, six ops behind
     //     each MFMA pair -- an MFMA holds the SIMD's issue port for 8 of its 32 cycles, so they cost nothing -- which needs two
     //     accumulator sets: tile 0 of a stage fills set A while set B (tile 1 of the stage before) is consumed, and vice versa;
@@ -931,13 +931,17 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
     };
     auto compute = [&]() {
         auto rd = [&](int g) { return *(const v4i*)(lds + rd_off[(g % 12) & 3] + ((g / 12) * TILE_BYTES + 128 * ((g % 12) >> 2))); };
-        v4i bq[3];
-        bq[0] = rd(0); bq[1] = rd(1);
+#ifndef H4_AHEAD
+#define H4_AHEAD 1             // K-steps a train fragment is read ahead of its MFMAs: 1, 2 and 3 measured the same (1.36-1.37 ms), 1 leaves 8 registers of margin
+#endif
+        v4i bq[H4_AHEAD + 1];
+#pragma unroll
+        for (int g = 0; g < H4_AHEAD; ++g) bq[g] = rd(g);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int tile = (g / 12) & 1, s = g % 12;     // accumulator set by tile parity
-            if (g + 2 < NG && !((H4_EXP & 8) && g >= 1)) bq[(g + 2) % 3] = rd(g + 2);
-            const v4i b4 = bq[g % 3];
+            if (g + H4_AHEAD < NG && !((H4_EXP & 8) && g >= 1)) bq[(g + H4_AHEAD) % (H4_AHEAD + 1)] = rd(g + H4_AHEAD);
+            const v4i b4 = bq[g % (H4_AHEAD + 1)];
             const v8i b8 = { b4[0], b4[1], b4[2], b4[3], 0, 0, 0, 0 };
             const v8i a0 = { afrag[0][s][0], afrag[0][s][1], afrag[0][s][2], afrag[0][s][3], 0, 0, 0, 0 };
             const v8i a1 = { afrag[1][s][0], afrag[1][s][1], afrag[1][s][2], afrag[1][s][3], 0, 0, 0, 0 };
