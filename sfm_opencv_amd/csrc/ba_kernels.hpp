@@ -727,12 +727,15 @@ __device__ __forceinline__ void ba_schur_role(const BADev& P, const int4* __rest
         double Vi[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Vi[i] = P.Vinv[6 * (size_t)p + i];
+        // both pixels requested here, with the point's records: the second one used to be fetched between the two linearisations
+        // (C5: 0.69 -> 0.66 ms for the linearisation phase)
+        const double ui = P.ouv[2 * ki], vi = P.ouv[2 * ki + 1], uj = P.ouv[2 * kj], vj = P.ouv[2 * kj + 1];
         // T_i W_j' = Ec_a' (F_a V^-1 F_b') Ec_b: 2x2 core first, then 2x6, then the 6x6 outer product (126 fma against
         // 234 for the 6x3 forms)
         double G[2][3], Ea[2][6];
         {
             ObsLin o;
-            obs_linearize(P.K, P.campre + CAMPRE * (size_t)ca, P.ext + 6 * ca + 3, X, P.ouv[2 * ki], P.ouv[2 * ki + 1], P.huber_a, nullptr, P.scale_c + oa, spp, o);
+            obs_linearize(P.K, P.campre + CAMPRE * (size_t)ca, P.ext + 6 * ca + 3, X, ui, vi, P.huber_a, nullptr, P.scale_c + oa, spp, o);
             symv3(Vi, o.F[0], G[0]);
             symv3(Vi, o.F[1], G[1]);
 #pragma unroll
@@ -741,7 +744,7 @@ __device__ __forceinline__ void ba_schur_role(const BADev& P, const int4* __rest
         double N0[6], N1[6];
         {
             ObsLin o;
-            obs_linearize(P.K, P.campre + CAMPRE * (size_t)cb, P.ext + 6 * cb + 3, X, P.ouv[2 * kj], P.ouv[2 * kj + 1], P.huber_a, nullptr, P.scale_c + ob, spp, o);
+            obs_linearize(P.K, P.campre + CAMPRE * (size_t)cb, P.ext + 6 * cb + 3, X, uj, vj, P.huber_a, nullptr, P.scale_c + ob, spp, o);
             const double m00 = G[0][0] * o.F[0][0] + G[0][1] * o.F[0][1] + G[0][2] * o.F[0][2];
             const double m01 = G[0][0] * o.F[1][0] + G[0][1] * o.F[1][1] + G[0][2] * o.F[1][2];
             const double m10 = G[1][0] * o.F[0][0] + G[1][1] * o.F[0][1] + G[1][2] * o.F[0][2];
@@ -802,13 +805,16 @@ __global__ __launch_bounds__(256, 3) void ba_camschur_kernel(BADev P, int n_cam_
     if (upto > before) ba_camera_role(P, red, before * 8 + (blockIdx.x & 7), n_cam_blocks);
     else ba_schur_role(P, chunk_desc, n_chunk, items, part, (g - before) * 8 + (blockIdx.x & 7), gridDim.x - n_cam_blocks);
 }
-// the two roles as launches of their own: large problems run them on two streams (see enqueue_build)
-__global__ __launch_bounds__(256, 3) void ba_camera_kernel(BADev P)
+// the two roles as launches of their own: large problems run them on two streams (see enqueue_build).  Compiled for TWO waves per SIMD
+// (256 registers, nothing spilled), unlike the one-launch form above: at C5, where the gathers miss the L2s, the linearisation phase
+// runs 0.746 -> 0.66 ms that way (three waves: 168 registers and up to ten spilled); at C4 the one-launch form measured 82 us at three
+// waves against 84 at two.  Reading a trip's gathers one trip ahead (both kernels, round 3) lost in every combination: 0.68-0.77 ms.
+__global__ __launch_bounds__(256, 2) void ba_camera_kernel(BADev P)
 {
     __shared__ double red[4][CAMACC];
     ba_camera_role(P, red, blockIdx.x, gridDim.x);
 }
-__global__ __launch_bounds__(256, 3) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
+__global__ __launch_bounds__(256, 2) void ba_schur_kernel(BADev P, const int4* __restrict__ chunk_desc, int n_chunk,
                                                        const int4* __restrict__ items, double* __restrict__ part)
 {
     ba_schur_role(P, chunk_desc, n_chunk, items, part, blockIdx.x, gridDim.x);
