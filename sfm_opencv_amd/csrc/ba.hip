@@ -1395,6 +1395,7 @@ int sfmhip_ba_create(sfmhip_ctx* ctx, const double* K4, const double* ext6, int 
     h->arena_chunk = (size_t)n_pt * 360 + (size_t)n_obs * 72 + (size_t)n_cam * 4096 + (1u << 20);
 #ifdef SFMHIP_EXPERIMENTS
     h->force_dense = getenv("SFMHIP_DENSE_SOLVER") != nullptr;
+    if (const char* e = getenv("SFMHIP_FUSE_MAX_BLOCKS")) h->fuse_max_blocks = atoi(e);      // measurement knob: 0 = always two launches on two streams
 #endif
 
     int rc = SFMHIP_OK;
