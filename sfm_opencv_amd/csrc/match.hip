@@ -792,8 +792,7 @@ __global__ __launch_bounds__(256) void knn2_hamming2_kernel(const PairDesc* __re
 // ------------------------------------------------------------------------------------------------
 // Hamming2 kNN-2 on the matrix cores: v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands (rows from prep_hamming_fp4_kernel).
 // grid = (query blocks of 64 NW rows, chunks, pairs [padded to 8]), block = NW waves x 64 query rows; NW = 8 (512 rows, one workgroup
-// per CU) is what runs: a staged train row then serves 512 queries, and every wave issues 3 LDS-DMA pieces per stage instead of 6
-// -- the issue cost of those pieces was 22 % of the 4-wave kernel (experiments: H4_EXP).
+// per CU) is what runs: a staged train row then serves 512 queries (half the L2 requests of NW = 4, which measures the same time).
 //   * the wave's 64 query rows stay in registers for the whole chunk: 2 tiles x 12 K-steps x 4 dwords = 96 VGPRs, sign bits
 //     flipped (the accumulator then holds MINUS the dot product), spare values replaced by the weights below;
 //   * train rows stream through LDS by LDS-DMA, 64 rows (24 KB, back to back) per stage, two stages in flight; the 16-byte chunks of
