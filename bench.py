@@ -48,6 +48,7 @@ SOLVER_KERNEL = "chol_node_forward_kernel"     # the leaf level of the dissectio
 RECORDED_TRAFFIC = {"knn2_i8_kernel<4>": (3.045e8, "profiles/r03_traffic_pmc.md"),
                     "distmat_i8_kernel<4>": (4.881e8, "profiles/r03_traffic_pmc.md"),
                     "knn2_hamming2_kernel": (6.368e8, "profiles/r03_traffic_pmc.md"),     # the VALU kernel (62..64-byte rows), not on the bench path any more
+                    "knn2_hamming2_fp4_kernel": (8.934e8, "profiles/r03_hamming_fp4.md"),  # 2 x 428,280 KiB FETCH_SIZE (LDS-DMA row streams) + 15,920 KiB WRITE_SIZE
                     "ba_camschur_kernel": (9.94e7, "profiles/r03_traffic_pmc.md")}      # 2 x FETCH_SIZE (streaming reads; raw for gathers / scalar loads) + WRITE_SIZE
 
 
@@ -533,7 +534,9 @@ def main():
                         "peak": FP4_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (ham_net * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS,
                         "algorithmic_ops": flops, "avg_launch_ms": ham["kernel_ms"], "event_bracket_overhead_ms": ev_overhead_ms,
                         "avg_launch_ms_net": ham_net, "launches_timed": int(ham["calls"]), "merge_ms": ham["merge_ms"],
-                        "traffic": None,
+                        "traffic": RECORDED_TRAFFIC["knn2_hamming2_fp4_kernel"][0] if (world == 1 and args.config == "C4") else None,
+                        "traffic_source": (RECORDED_TRAFFIC["knn2_hamming2_fp4_kernel"][1] + " (recorded by separate --pmc passes, not measured in this run)") if (world == 1 and args.config == "C4") else None,
+                        "algorithmic_bytes": 2.0 * 384 * n_desc * n_pairs_l + 16.0 * n_desc * n_pairs_l,
                         "issued": "12 K-steps x 2 MFMAs of 32 cycles per (64 queries x 32 trains) on padded 5120-row sets: 1.91e6 matrix-pipe cycles per SIMD and launch "
                                   "(SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_hamming_fp4_pmc.md) = 0.80 ms at 2.4 GHz",
                         "note": "one launch = all chain pairs of this rank; the VALU popcount kernel of rounds 1-2 (knn2_hamming2_kernel, 3.33 ms, still used "
