@@ -207,6 +207,35 @@ def test_c5_pair_knn_oracle_slice(ctx):
         assert np.sqrt(((a[i] - b[perm[gi2[i, 1]]]) ** 2).sum(dtype=np.float64)) == np.sqrt(((a[i] - b[gi[i, 1]]) ** 2).sum(dtype=np.float64))
 
 
+def test_c5_pair_hamming2_two_windows_oracle_slice_and_permutation(ctx):
+    """BASELINE.json configs[4] per-pair size on binary rows: 10k x 10k, 61 bytes -- the matrix-core kernel over two chunk windows
+    (8192 + 2048 rows, 8-bit tile index): an oracle slice, the VALU kernel on the same data, and the size-independent properties
+    (self match at distance 0; a permutation of the train rows permutes the answer up to ties)."""
+    import torch
+    d = synth.akaze_descriptor_chain(2, 10000, seed=4242)
+    a, b = d[0], d[1]
+    gi, gd = ctx.knn2_hamming2(a, b)
+    rows = np.random.default_rng(7).choice(10000, 200, replace=False)
+    oi, od = orc.knn2_hamming2(a[rows], b)
+    assert np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od)
+    qs = ctx.descset_hamming2(torch.from_numpy(a).cuda()); ts = ctx.descset_hamming2(torch.from_numpy(b).cuda())
+    idx = torch.empty((10000, 2), dtype=torch.int32, device="cuda"); dist = torch.empty((10000, 2), dtype=torch.float32, device="cuda")
+    ctx.knn2_dev(qs, ts, idx, dist, force_path=3)
+    ctx.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), gi) and np.array_equal(dist.cpu().numpy(), gd)
+    si, sd = ctx.knn2_hamming2(a, a)
+    if np.unique(a, axis=0).shape[0] == a.shape[0]:
+        assert np.array_equal(si[:, 0], np.arange(10000)) and not sd[:, 0].any()
+    perm = np.random.default_rng(8).permutation(10000)
+    gi2, gd2 = ctx.knn2_hamming2(a, b[perm])
+    assert np.array_equal(gd, gd2)                        # distances are permutation-invariant
+    clean = (gd[:, 0] != gd[:, 1])                        # integer distances tie often: compare the best index where it is unique
+    third_free = clean & (gd2[:, 0] != gd2[:, 1])
+    assert third_free.sum() > 5000 and np.array_equal(perm[gi2[third_free, 0]], gi[third_free, 0])
+    m = api.match_features(a, b, ctx=ctx)
+    assert len(m) > 4000 and np.array_equal(m, api.ratio_filter(gi, gd))
+
+
 @pytest.fixture(scope="module")
 def c5_scene():
     cfg = synth.CONFIGS["C5"]
