@@ -188,7 +188,8 @@ class Context:
         arr = (C.c_void_p * len(sets))(*[s.handle for s in sets])
         self._check(self.lib.sfmhip_match_pairs(self.h, arr, len(sets), pairs.ctypes.data, n_pairs,
                                                 ratio, floor_, mult, out.ctypes.data, mpp, counts.ctypes.data))
-        return [out[p, :counts[p]].copy() for p in range(n_pairs)]
+        # views into the one result buffer (a copy per pair cost 3.8 ms of a 13 ms C4 chain from host rows)
+        return [out[p, :c] for p, c in enumerate(counts.tolist())]
 
     def match_pairs_dev(self, sets, pairs, d_matches, max_per_pair, d_counts, ratio=0.6, floor_=10.0, mult=5.0):
         pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
