@@ -53,6 +53,10 @@ __global__ __launch_bounds__(NTILE) void normals_kernel(const double* __restrict
     double bd[KMAX]; int bi[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+    // Squared-distance gate in front of the exact test: sqrt(d2) < bd[last] is impossible once d2 > bd[last]^2 (1 + 2^-50) (the real
+    // root then exceeds bd[last], and rounding is monotone), so the fp64 square root -- two thirds of the instructions of a candidate --
+    // is taken only by candidates that can still enter the list.  Same K-sets, same order, bit for bit (round 3: 113 -> see profiles/).
+    double gate2 = INFINITY;
     for (int base = 0; base < n; base += NTILE) {
         const int j0 = base + threadIdx.x;
         __syncthreads();
@@ -62,7 +66,9 @@ __global__ __launch_bounds__(NTILE) void normals_kernel(const double* __restrict
         for (int t = 0; t < cnt; ++t) {
             const int j = base + t;
             const double dx = px - tx[t], dy = py - ty[t], dz = pz - tz[t];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 <= gate2)) continue;
+            const double d = sqrt(d2);
             if (j != i && d < bd[KMAX - 1]) {
                 bd[KMAX - 1] = d; bi[KMAX - 1] = j;
 #pragma unroll
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(NTILE) void normals_kernel(const double* __restrict
                         const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
                     }
                 }
+                gate2 = bd[KMAX - 1] * bd[KMAX - 1] * (1.0 + 0x1p-50);       // inf while the list is not full
             }
         }
     }
