@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256, KNN_WGS_PER_CU) void knn2_i8_kernel(const Pair
         // One tile at a time: 4 fragments, KS MFMAs, then the epilogue on the finished accumulator.  Nothing overlaps inside
         // the wave on purpose -- this form needs <= 128 VGPRs, and FOUR resident waves per SIMD overlap each other's MFMA,
         // VALU and LDS phases better than the software-pipelined 180-register form did with two (the epilogue mix issues at
-        // 2.0 ns per instruction per SIMD with 4 waves against 2.3 with 2, experiments/valu_bench.hip).
+        // 2.0 ns per instruction per SIMD with 4 waves against 2.3 with 2, experiments/valu_bench.hip).  Round 3 re-tried it the way the
+        // FP4 Hamming2 kernel does it -- tile t - 1's update dealt out behind the four MFMAs of tile t, two accumulator sets, 167
+        // registers = three waves per SIMD: 0.850-0.861 ms against 0.874-0.877 in the same call (2 %): not kept.
 #pragma unroll
         for (int tile = 0; tile < TILES; ++tile) {
             v4i bf[KS];
