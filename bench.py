@@ -358,6 +358,37 @@ def main():
         ham = dict(t=t_ham, blocks=t_ham_blocks, kernel_ms=ham_kernel_ms, merge_ms=ham_merge_ms, calls=ham_calls, matches=int(h_counts.sum().item()), chain=bchain)
         del bsets, d_bin
 
+    # ------------------------------------------------------------------ region E: two-view DLT triangulation (reconstruct, NView:1117-1159), resident inputs
+    tri = None
+    if rank == 0 and not args.no_match:
+        n_tri = n_pt
+        Kc = np.array([[sc["K0"][0], 0, sc["K0"][2]], [0, sc["K0"][1], sc["K0"][3]], [0, 0, 1]], np.float64)
+        def proj(ext6):
+            w = np.asarray(ext6[:3], np.float64); th = np.linalg.norm(w)
+            Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            R = np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
+            return (Kc @ np.concatenate([R, np.asarray(ext6[3:6], np.float64).reshape(3, 1)], 1)).astype(np.float32)
+        P1, P2 = proj(sc["ext0"].reshape(-1, 6)[0]), proj(sc["ext0"].reshape(-1, 6)[1])
+        X = np.concatenate([np.asarray(sc["pts0"], np.float64).reshape(-1, 3)[:n_tri], np.ones((n_tri, 1))], 1)
+        def pix(P):
+            h = X @ P.astype(np.float64).T
+            return (h[:, :2] / h[:, 2:3]).astype(np.float32)
+        d_xy1 = torch.from_numpy(pix(P1)).cuda(); d_xy2 = torch.from_numpy(pix(P2)).cuda()
+        d_xyzw = torch.empty((4, n_tri), dtype=torch.float32, device="cuda"); d_xyz = torch.empty((n_tri, 3), dtype=torch.float64, device="cuda")
+        for _ in range(5):
+            ctx.triangulate2_dev(P1, P2, d_xy1, d_xy2, d_xyzw, d_xyz)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ctx.triangulate2_dev(P1, P2, d_xy1, d_xy2, d_xyzw, d_xyz)
+        torch.cuda.synchronize()
+        t_tri = (time.perf_counter() - t0) / 50
+        tri = {"value": n_tri / t_tri, "unit": "points/s", "points_per_call": n_tri, "ms_per_call": 1e3 * t_tri, "calls_timed": 50,
+               "algorithmic_bytes_per_point": 56, "achieved_gbs": 56.0 * n_tri / t_tri / 1e9,
+               "what": "sfmhip_triangulate2_f32_dev: every scene point seen through cameras 0 and 1 (float32 projection matrices and pixels, fp64 Jacobi SVD of the 4x4 "
+                       "system per point, float32 homogeneous + fp64 de-homogenised output); 16 B in + 40 B out per point: a compute-bound kernel"}
+        del d_xy1, d_xy2, d_xyzw, d_xyz
+
     # ------------------------------------------------------------------ region C: the drop-in calls, from host arrays
     e2e = None
     if not args.no_end_to_end and rank == 0 and world == 1:
@@ -570,6 +601,7 @@ def main():
                  "matches_rank0": n_matches, "includes": "prep + kNN-2 + ratio tail + match lists in host memory (" + ("device buffers + one D2H copy" if args.staged_match_copy else "written to pinned host memory by the ratio-tail kernel") + ")"},
             "matched_pairs_per_sec_hamming2": ham_out,
             "roofline_hamming2": roof_ham,
+            "triangulated_points_per_sec": tri,
             "ba_solve_end_to_end": e2e,
             "roofline_gemm": gemm,
             "cpu_baseline": cpu,

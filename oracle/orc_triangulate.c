@@ -7,9 +7,11 @@
  *     A[2j+1][k] = y_j * P_j[2][k] - P_j[1][k]        j = 0,1 (views), k = 0..3
  * from float32 points and float32 3x4 projections, cv::SVD::compute(A, w, u, vt), output the last
  * row of vt (right singular vector of the smallest singular value) cast to the point type (float32).
- * The SVD here is a one-sided (Hestenes) Jacobi in double; OpenCV's JacobiSVD differs in sweep
- * order, so the null vector agrees to ~1e-15*cond and in sign only up to +-1 (the sign cancels in
- * the division by w, NView:1154).
+ * The SVD here is a one-sided (Hestenes) Jacobi in double with OpenCV's own stopping rule for double input
+ * (JacobiSVDImpl_ [3P]: a column pair is left alone once |a_p . a_q| <= 10 DBL_EPSILON sqrt(|a_p|^2 |a_q|^2), at most
+ * 30 sweeps; rounds 1-2 used 1e-16 -- below the rounding noise of the dot product, so most systems ran all 30 sweeps);
+ * OpenCV's JacobiSVD differs in sweep order, so the null vector agrees to ~1e-15*cond and in sign only up to +-1 (the
+ * sign cancels in the division by w, NView:1154).
  * De-homogenisation NView:1153-1155: `Mat_<float> /= w` is convertTo(alpha = 1./w) [3P], i.e. a
  * float multiply by (float)(1.0/(double)w); then Point3f -> Point3d.
  * parity unpinned; cross-checked vs numpy.linalg.svd in tests/.
@@ -17,6 +19,8 @@
 #include "orc.h"
 #include <math.h>
 #include <stdlib.h>
+#include <float.h>
+#define ORC_SVD_EPS (10.0 * DBL_EPSILON)
 
 /* null vector (unit 2-norm) of a 4x4 matrix: right singular vector of the smallest singular value */
 static void null_vector4(const double Ain[16], double v[4])
@@ -30,7 +34,7 @@ static void null_vector4(const double Ain[16], double v[4])
             for (int q = p + 1; q < 4; ++q) {
                 double a = 0, b = 0, g = 0;
                 for (int i = 0; i < 4; ++i) { a += A[i][p] * A[i][p]; b += A[i][q] * A[i][q]; g += A[i][p] * A[i][q]; }
-                if (fabs(g) <= 1e-16 * sqrt(a * b) || g == 0.0) continue;
+                if (fabs(g) <= ORC_SVD_EPS * sqrt(a * b) || g == 0.0) continue;
                 rotated = 1;
                 double zeta = (b - a) / (2.0 * g);
                 double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -15,6 +15,10 @@
 #include <cmath>
 #include <vector>
 
+// OpenCV's stopping rule for double input (JacobiSVDImpl_ [3P]: eps = 10 DBL_EPSILON).  Rounds 1-2 used 1e-16, below the rounding
+// noise of the dot product: most systems then ran all 30 sweeps (300k points: 0.32 ms; with this rule: see profiles/README.md).
+#define SVD_EPS (10.0 * 2.220446049250313e-16)
+
 struct ProjPair { float p1[12]; float p2[12]; };
 
 __device__ __forceinline__ void jacobi_rot(double (&A)[4][4], double (&V)[4][4], const int p, const int q, bool& rotated)
@@ -22,7 +26,7 @@ __device__ __forceinline__ void jacobi_rot(double (&A)[4][4], double (&V)[4][4],
     double a = 0.0, b = 0.0, g = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a += A[i][p] * A[i][p]; b += A[i][q] * A[i][q]; g += A[i][p] * A[i][q]; }
-    if (fabs(g) <= 1e-16 * sqrt(a * b) || g == 0.0) return;
+    if (fabs(g) <= SVD_EPS * sqrt(a * b) || g == 0.0) return;
     rotated = true;
     const double zeta = (b - a) / (2.0 * g);
     const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
