@@ -1,0 +1,163 @@
+// CPU check of csrc/ba_chain.hpp: the chain solver's kernels compiled with -DCHAIN_HOST_EMU run on a fiber emulation of a
+// workgroup (one ucontext per GPU thread; a wave's lanes run to their next synchronisation point one after the other) and
+// are compared with a dense Cholesky solve of the same damped band + border system.  What this pins: every index formula
+// of the solver (ring slots, block offsets, hand-over maps, factor records, back-substitution positions) for many shapes
+// (w, leaves, levels inside the first kernel, with / without intrinsics, ragged leaves).  What it cannot pin: anything
+// that depends on the hardware's execution (LDS ordering inside a wave, register pressure) -- tests/test_ba_gpu.py does.
+//
+//   usage: chain_emu_test            all shapes, prints one line each, exit code 1 on a mismatch
+#include <ucontext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+#define CHAIN_HOST_EMU
+namespace chain_emu {
+struct Fiber { ucontext_t ctx; std::vector<char> stack; int state = 0; };      // 0 runnable, 1 at a wave sync, 2 at a workgroup sync, 3 done
+static std::vector<Fiber> fibers;
+static ucontext_t sched;
+static int cur = 0, block_id = 0;
+static std::function<void()> body;
+static double shfl_buf[1024];
+int tid() { return cur; }
+int bid() { return block_id; }
+static void yield(int st) { fibers[cur].state = st; swapcontext(&fibers[cur].ctx, &sched); }
+void sync_wg() { yield(2); }
+void sync_wave() { yield(1); }
+double shfl_xor(double v, int mask) { shfl_buf[cur] = v; yield(1); const double r = shfl_buf[cur ^ mask]; yield(1); return r; }
+static void entry() { body(); fibers[cur].state = 3; swapcontext(&fibers[cur].ctx, &sched); }
+static void run_block(int bid_, int nthreads, std::function<void()> fn)
+{
+    block_id = bid_; body = fn;
+    fibers.clear(); fibers.resize(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = fibers[t];
+        f.stack.resize(256 << 10);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = &sched;
+        makecontext(&f.ctx, entry, 0);
+    }
+    const int nw = nthreads / 64;
+    for (;;) {
+        for (int wv = 0; wv < nw; ++wv) {
+            for (;;) {
+                for (int l = 0; l < 64; ++l) { cur = wv * 64 + l; if (fibers[cur].state == 0) swapcontext(&sched, &fibers[cur].ctx); }
+                int n1 = 0, n2 = 0, n3 = 0;
+                for (int l = 0; l < 64; ++l) { const int s = fibers[wv * 64 + l].state; n1 += s == 1; n2 += s == 2; n3 += s == 3; }
+                if (n1 + n3 == 64 && n1 > 0) { for (int l = 0; l < 64; ++l) if (fibers[wv * 64 + l].state == 1) fibers[wv * 64 + l].state = 0; continue; }
+                if (n2 + n3 == 64) break;
+                fprintf(stderr, "emulation: wave %d diverged at a synchronisation point (%d wave, %d workgroup, %d done)\n", wv, n1, n2, n3); exit(2);
+            }
+        }
+        int done = 0;
+        for (auto& f : fibers) done += f.state == 3;
+        if (done == nthreads) break;
+        if (done != 0) {
+            // some waves finished while others wait at a workgroup barrier: allowed only if whole waves are done
+            for (int wv = 0; wv < nw; ++wv) { int d = 0; for (int l = 0; l < 64; ++l) d += fibers[wv * 64 + l].state == 3; if (d != 0 && d != 64) { fprintf(stderr, "emulation: partial wave exit\n"); exit(2); } }
+        }
+        for (auto& f : fibers) if (f.state == 2) f.state = 0;
+    }
+}
+}
+
+#include "../../sfm_opencv_amd/csrc/ba_chain.hpp"
+
+static bool run_case(int ncf, int w, int nk, int force_P, int force_a, int force_G, bool predamped, unsigned seed, bool verbose)
+{
+    const int n = 6 * ncf + nk, npad = (n + 31) / 32 * 32, ld = npad;
+    ChainArgs A; memset(&A, 0, sizeof A);
+    if (!chain_plan(A, ncf, w, nk, ld, npad, force_P, force_a, force_G, (size_t)160 << 10)) { printf("ncf %d w %d nk %d P %d a %d: no plan\n", ncf, w, nk, force_P, force_a); return true; }
+    // random band + border system: S = J'J of a random "observation" structure keeps it positive semi-definite, the damping makes it definite
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    std::vector<double> S((size_t)npad * ld, 0.0), rhs(npad, 0.0), diagU(npad, 0.0);
+    for (int i = 0; i < ncf; ++i)
+        for (int rep = 0; rep < 3; ++rep) {
+            // a random row touching cameras i .. i + span (span <= w) and the intrinsics
+            const int span = (int)(rng() % (unsigned)(w + 1));
+            std::vector<std::pair<int, double>> row;
+            for (int c = i; c <= i + span && c < ncf; ++c) for (int k = 0; k < 6; ++k) row.push_back({ 6 * c + k, U(rng) });
+            for (int k = 0; k < nk; ++k) row.push_back({ 6 * ncf + k, 0.3 * U(rng) });
+            const double res = U(rng);
+            for (auto& a : row) { for (auto& b : row) S[(size_t)a.first * ld + b.first] += a.second * b.second; rhs[a.first] += a.second * res; diagU[a.first] += a.second * a.second; }
+        }
+    // one camera nobody observes (unit row rule), when there is room for it
+    int dead = -1;
+    if (ncf > 4 * w + 6 && (seed & 1)) {
+        dead = ncf / 2;
+        for (int k = 0; k < 6; ++k) { const int p = 6 * dead + k; for (int j = 0; j < npad; ++j) { S[(size_t)p * ld + j] = 0.0; S[(size_t)j * ld + p] = 0.0; } rhs[p] = 0.0; diagU[p] = 0.0; }
+        for (int c = 0; c < ncf; ++c) if (c != dead) for (int k = 0; k < 6; ++k) { double d = 0; (void)d; }
+    }
+    const double radius = 1e2, dmin = 1e-6, dmax = 1e32;
+    // reference: dense Cholesky of the damped system
+    std::vector<double> D((size_t)n * n), yref(n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) D[(size_t)i * n + j] = S[(size_t)i * ld + j];
+    for (int i = 0; i < n; ++i) { if (diagU[i] > 0.0) D[(size_t)i * n + i] += std::min(std::max(diagU[i], dmin), dmax) / radius; else D[(size_t)i * n + i] = 1.0; }
+    std::vector<double> Sin = S;
+    if (predamped) for (int i = 0; i < n; ++i) Sin[(size_t)i * ld + i] = D[(size_t)i * n + i];
+    {
+        std::vector<double> Lm = D;
+        for (int j = 0; j < n; ++j) {
+            double d = Lm[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) d -= Lm[(size_t)j * n + k] * Lm[(size_t)j * n + k];
+            if (!(d > 0)) { printf("reference: not positive definite\n"); return false; }
+            const double l = std::sqrt(d); Lm[(size_t)j * n + j] = l;
+            for (int i = j + 1; i < n; ++i) { double s = Lm[(size_t)i * n + j]; for (int k = 0; k < j; ++k) s -= Lm[(size_t)i * n + k] * Lm[(size_t)j * n + k]; Lm[(size_t)i * n + j] = s / l; }
+        }
+        std::vector<double> z(n);
+        for (int i = 0; i < n; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= Lm[(size_t)i * n + k] * z[k]; z[i] = s / Lm[(size_t)i * n + i]; }
+        for (int i = n - 1; i >= 0; --i) { double s = z[i]; for (int k = i + 1; k < n; ++k) s -= Lm[(size_t)k * n + i] * yref[k]; yref[i] = s / Lm[(size_t)i * n + i]; }
+    }
+    std::vector<double> rec((size_t)ncf * A.rec_stride, 0.0), img((size_t)(A.P >> A.a) * A.img_doubles + 8, 0.0), y(npad, -7.0);
+    int err = 0;
+    A.S = Sin.data(); A.rhs = rhs.data(); A.diagU = predamped ? nullptr : diagU.data();
+    A.inv_radius = 1.0 / radius; A.dmin = dmin; A.dmax = dmax;
+    A.rec = rec.data(); A.img = img.data(); A.y = y.data(); A.err = &err;
+    {
+        std::vector<double> smem(ch_sub_lds(A.w, A.BB, A.a, A.G, A.n, A.a == A.m) + 16);
+        for (int b = 0; b < (A.P >> A.a); ++b) {
+            for (auto& v : smem) v = std::nan("");          // stale LDS must never be read
+            chain_emu::run_block(b, 64 * A.G << A.a, [&] { chain_sub_body(A, smem.data()); });
+        }
+    }
+    if (A.a < A.m) {
+        std::vector<double> smem(ch_top_lds(A.w, A.BB, A.m - A.a, A.nw_top, A.n) + 16, std::nan(""));
+        chain_emu::run_block(0, 64 * A.nw_top, [&] { chain_top_body(A, smem.data()); });
+    }
+    double emax = 0.0, ymax = 0.0;
+    for (int i = 0; i < n; ++i) { emax = std::max(emax, std::fabs(y[i] - yref[i])); ymax = std::max(ymax, std::fabs(yref[i])); if (y[i] != y[i]) emax = 1e300; }
+    bool pads_zero = true;
+    for (int i = n; i < npad; ++i) pads_zero = pads_zero && y[i] == 0.0;
+    const bool ok = err == 0 && emax <= 1e-9 * (1.0 + ymax) && pads_zero;
+    if (verbose || !ok)
+        printf("%s ncf %4d w %d nk %d  P %2d a %d G %d (levels on top %d) q %d r %d%s%s: max |y - y_ref| = %.3e (|y| <= %.3e) err %d\n", ok ? "ok  " : "FAIL", ncf, w, nk, A.P, A.a, A.G, A.m - A.a,
+               A.q, A.r, predamped ? " predamped" : "", dead >= 0 ? " dead-camera" : "", emax, ymax, err);
+    return ok;
+}
+
+int main(int argc, char** argv)
+{
+    const bool verbose = argc > 1;
+    bool ok = true;
+    unsigned seed = 1;
+    // the benchmark shapes and the small ones around them
+    struct C { int ncf, w, nk, P, a, G; };
+    const C cases[] = {
+        { 1, 1, 4, 0, -1, 0 }, { 2, 1, 4, 0, -1, 1 }, { 3, 2, 0, 0, -1, 2 }, { 6, 3, 4, 0, -1, 0 }, { 6, 3, 4, 0, -1, 1 }, { 7, 6, 4, 0, -1, 0 }, { 10, 3, 4, 0, -1, 2 }, { 23, 3, 4, 0, -1, 0 }, { 23, 3, 0, 0, -1, 1 },
+        { 49, 3, 4, 0, -1, 0 }, { 49, 3, 4, 2, 1, 0 }, { 49, 3, 4, 2, 0, 0 }, { 49, 3, 4, 4, 0, 1 }, { 49, 3, 4, 4, 1, 2 }, { 49, 3, 4, 4, 2, 1 }, { 49, 3, 0, 4, 2, 2 },
+        { 50, 1, 4, 0, -1, 0 }, { 50, 2, 4, 0, -1, 0 }, { 60, 4, 4, 0, -1, 0 }, { 61, 4, 0, 8, 1, 1 }, { 61, 4, 4, 8, 1, 4 },
+        { 119, 3, 4, 0, -1, 0 }, { 119, 3, 4, 8, 0, 4 }, { 119, 3, 4, 8, 1, 2 }, { 119, 3, 4, 8, 2, 2 }, { 119, 3, 4, 16, 2, 1 }, { 119, 3, 4, 16, 1, 4 },
+        { 199, 3, 4, 0, -1, 0 }, { 199, 3, 4, 32, 2, 2 }, { 199, 3, 0, 16, 2, 1 }, { 200, 2, 4, 32, 2, 0 }, { 999, 3, 4, 0, -1, 0 },
+    };
+    for (const C& c : cases) {
+        ok = run_case(c.ncf, c.w, c.nk, c.P, c.a, c.G, false, seed, verbose) && ok; ++seed;
+    }
+    ok = run_case(49, 3, 4, 4, 2, 0, true, 77, verbose) && ok;
+    ok = run_case(199, 3, 4, 0, -1, 0, true, 78, verbose) && ok;
+    printf(ok ? "chain solver emulation: all shapes agree with the dense solve\n" : "chain solver emulation: MISMATCH\n");
+    return ok ? 0 : 1;
+}
