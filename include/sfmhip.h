@@ -201,6 +201,10 @@ typedef struct {
     int    linearizer;                  /* 0    how the reduced system is built (same result up to rounding): 0 / 1 = per-observation
                                          *      kernels; 2 = run tiles (points sharing a camera list linearised once, reduced on the
                                          *      matrix pipe) when every point has 1..7 observations, else the per-observation kernels */
+    int    solver;                      /* 0    reduced camera solve (same result up to rounding): 0 = the chain solver (csrc/ba_chain.hpp: fronts
+                                         *      in LDS, a camera at a time, two launches) where the cameras form a chain of band width <= 3
+                                         *      cameras and at most 640 of them are free, else 1; 1 = nested dissection, one launch per tree
+                                         *      level (csrc/ba_solver.hpp; the only solver of rounds 1-3), dense blocked fallback */
 } sfm_ba_options;
 
 #define SFMHIP_BA_CONVERGENCE     0

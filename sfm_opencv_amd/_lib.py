@@ -25,7 +25,7 @@ class BAOptions(C.Structure):
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("huber_delta", C.c_double),
                 ("jacobi_scaling", C.c_int), ("fix_first_camera", C.c_int), ("fix_intrinsics", C.c_int),
-                ("verbose", C.c_int), ("linearizer", C.c_int)]
+                ("verbose", C.c_int), ("linearizer", C.c_int), ("solver", C.c_int)]
 
 
 class BASummary(C.Structure):

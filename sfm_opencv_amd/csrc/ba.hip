@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "ba_kernels.hpp"
 #include "ba_solver.hpp"
+#include "ba_chain.hpp"
 #include "ba_tiles.hpp"
 #include "ba_setup.hpp"
 #include <algorithm>
@@ -239,6 +240,9 @@ struct sfmhip_ba {
     int *d_rd_start = nullptr, *d_rd_dst = nullptr, *d_rd_dst2 = nullptr; unsigned* d_rd_src = nullptr; int rd_nd = 0, rd_n_long = 0;
     size_t rd_dst_cap = 0, rd_src_cap = 0;
     std::vector<int> tile_tab_cam_pos; int tile_tab_npad = -1;      // the layout the fold table was built for
+    // chain solver (ba_chain.hpp): plan, factor records, the sub-trees' exported fronts
+    bool use_chain = false; ChainArgs chain; double *d_chain_rec = nullptr, *d_chain_img = nullptr; size_t chain_rec_cap = 0, chain_img_cap = 0;
+    size_t chain_lds1 = 0, chain_lds2 = 0;
     bool built = false; int build_parity = 0;    // d_msg holds the undamped linearisation at the CURRENT parameters (set by a speculative build)
     double phase_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int phase_cnt = 0;
 };
@@ -425,6 +429,21 @@ static int enqueue_solve(sfmhip_ba* h)
     hipStream_t st = ctx->stream;
     double* S = h->d_msg;
     const int nb = h->nbk, ld = h->npad;
+    if (h->use_chain) {
+        // chain solver: reads S, rhs and diagU (never writes them), factor records and exported fronts in its own buffers
+        ChainArgs A = h->chain;
+        A.S = S; A.rhs = h->d_msg + (size_t)h->npad * h->npad; A.diagU = nullptr; A.inv_radius = 1.0; A.dmin = A.dmax = 0.0;
+        if (h->solver_damps) {
+            BADev P = make_dev(h, h->damp_radius);
+            A.diagU = P.diagU; A.inv_radius = 1.0 / h->damp_radius; A.dmin = P.min_diag; A.dmax = P.max_diag;
+            h->solver_damps = false;
+        }
+        A.rec = h->d_chain_rec; A.img = h->d_chain_img; A.y = h->d_y; A.err = h->d_err; A.stamps = nullptr;
+        hipLaunchKernelGGL(chain_sub_kernel, dim3(A.P >> A.a), dim3(64 * A.G << A.a), h->chain_lds1, st, A);
+        if (A.a < A.m) hipLaunchKernelGGL(chain_top_kernel, dim3(1), dim3(64 * A.nw_top), h->chain_lds2, st, A);
+        SFM_HIP_TRY(ctx, hipGetLastError());
+        return SFMHIP_OK;
+    }
     if (h->use_sparse) {
         double* rhs_rw = h->d_msg + (size_t)h->npad * h->npad;
         SolverPlan pl; pl.prow_start = h->d_prow_start; pl.prow = h->d_prow; pl.nb = nb; pl.top_blk = h->top_blk; pl.linv = h->d_Linv;
@@ -505,7 +524,8 @@ static int enqueue_back(sfmhip_ba* h, double radius)
     const bool fuse_publish = !h->ar_fn && h->publish_in_back;
     size_t n0 = 0, n1 = 0;
     if (fuse_publish) {
-        n0 = (size_t)h->npad * h->npad;
+        // (the chain solver leaves S as the build wrote it, and the next build stores every entry it can populate: nothing to clear)
+        n0 = h->use_chain ? 0 : (size_t)h->npad * h->npad;
         if (h->use_sparse && h->nseg > 1 && h->d_topbuf) { n1 = h->topbuf_count & ~(size_t)1; h->top_cleared = (n1 == h->topbuf_count); }
         h->cleared = true;
     }
@@ -560,10 +580,25 @@ static int build_solver_plan(sfmhip_ba* h)
     int w = 0;
     for (int a = 0; a < ncf; ++a) for (int c = 0; c < a; ++c) if (adj[(size_t)a * ncf + c] != 0.0) w = std::max(w, a - c);
 
+    // The chain solver (ba_chain.hpp) takes the natural layout (cameras in chain order, no padding inside).  It applies to bands of
+    // at most CH_WMAX = 3 cameras (tracks of up to four frames): its fronts then have <= 59 rows, one lane each.  Measured in the LM
+    // loop on such scenes (experiments/_chk_chain.py, MI355X): reduced solve 0.094 against 0.128 ms at 200 cameras, 0.071 against
+    // 0.084 ms at 50, 0.044 against 0.047 ms at 24, 0.025 against 0.022 ms at 8 -- hence from 12 free cameras on.  Beyond ~640 cameras
+    // its leaves get long (32 leaves at most, two waves each) and the level-per-launch solver, whose leaves are throughput-bound
+    // panels, is level with it again (999 cameras: 242 us against 238 us).  SURVEY 8d's scenes (tracks of 2..6 frames: band 5) stay
+    // with the solver below: at that width a separator is one 32-column MFMA panel there and five serial camera steps here.
+    h->use_chain = false;
+    ChainArgs chain_args;
+    memset(&chain_args, 0, sizeof chain_args);
+    bool chain_ok = false;
+    if (h->o.solver == 0 && !h->force_dense && ncf >= 12 && ncf <= 640) {
+        const int npad_nat = std::max(NB, round_up(6 * ncf + (h->fixK ? 0 : 4), NB));
+        chain_ok = npad_nat <= h->npad_max && chain_plan(chain_args, ncf, w, h->fixK ? 0 : 4, npad_nat, npad_nat, 0, -1, 0, (size_t)160 << 10);
+    }
     // candidate configurations (leaves, parallel separator levels), best first
     struct Cfg { int P, Lp; };
     std::vector<Cfg> cfgs;
-    {
+    if (!chain_ok) {
         int P0 = std::min(solver_pick_leaves(ncf, w), h->solver_pmax), Lp0 = -1;
 #ifdef SFMHIP_EXPERIMENTS
         if (const char* e = getenv("SFMHIP_ND_LEAVES")) { int v = std::max(1, atoi(e)); P0 = 1; while (P0 * 2 <= v && P0 * 2 <= h->solver_pmax) P0 *= 2; }
@@ -576,8 +611,8 @@ static int build_solver_plan(sfmhip_ba* h)
             cfgs.push_back({ P, Lp });
             if (Lp > 0 && Lp0 < 0) cfgs.push_back({ P, 0 });
         }
-        cfgs.push_back({ 1, 0 });
     }
+    cfgs.push_back({ 1, 0 });
     for (const Cfg cfg : cfgs) {
         const int P = cfg.P, Lp = cfg.Lp;
         if (P > 1 && (w < 1 || (ncf - (P - 1) * w) / P < 1)) continue;
@@ -795,6 +830,18 @@ static int build_solver_plan(sfmhip_ba* h)
         }
         h->msg_count = (size_t)h->npad * h->npad + 3 * (size_t)h->npad + SCAL_GMAX_SLOTS + 64;
         h->n_sblk = (int)sblk.size() / 2;
+        if (chain_ok && P == 1) {
+            h->chain = chain_args;
+            h->chain_lds1 = 8 * ch_sub_lds(chain_args.w, chain_args.BB, chain_args.a, chain_args.G, chain_args.n, chain_args.a == chain_args.m);
+            h->chain_lds2 = chain_args.a < chain_args.m ? 8 * ch_top_lds(chain_args.w, chain_args.BB, chain_args.m - chain_args.a, chain_args.nw_top, chain_args.n) : 0;
+            const size_t nrec = (size_t)ncf * chain_args.rec_stride, nimg = (size_t)(chain_args.P >> chain_args.a) * chain_args.img_doubles + 8;
+            int rc = SFMHIP_OK;
+            if (nrec > h->chain_rec_cap) { rc = dalloc(h, &h->d_chain_rec, nrec); if (rc) return rc; h->chain_rec_cap = nrec; }
+            if (nimg > h->chain_img_cap) { rc = dalloc(h, &h->d_chain_img, nimg); if (rc) return rc; h->chain_img_cap = nimg; }
+            SFM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)chain_sub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));      // the largest any plan asks for: problems with different plans may be alive together
+            SFM_HIP_TRY(ctx, hipFuncSetAttribute((const void*)chain_top_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+            h->use_chain = true;
+        }
         {
             int rc = SFMHIP_OK;
             if (sblk.size() > h->sblk_cap) { rc = dalloc(h, &h->d_sblk, sblk.size()); if (rc) return rc; h->sblk_cap = sblk.size(); }     // re-planning (set_allreduce, reset) reuses it
@@ -803,6 +850,12 @@ static int build_solver_plan(sfmhip_ba* h)
             if (need > h->pack_cap) { rc = dalloc(h, &h->d_pack, need); if (rc) return rc; h->pack_cap = need; }
         }
         SFM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h->o.verbose)
+            printf("[sfmhip_ba] reduced system: %d unknowns (%d free cameras, band %d cameras); solver: %s\n", h->n, ncf, w,
+                   h->use_chain ? "chain (fronts in LDS)" : h->use_sparse ? (P > 1 ? "nested dissection, a launch per level" : "one workgroup, sparse panels") : "dense blocked");
+        if (h->use_chain && h->o.verbose)
+            printf("[sfmhip_ba] chain solver: %d leaves of %d-%d cameras, %d waves each, %d tree level(s) in the first kernel, %d in the second\n",
+                   h->chain.P, h->chain.q, h->chain.q + (h->chain.r ? 1 : 0), h->chain.G, h->chain.a, h->chain.m - h->chain.a);
         return SFMHIP_OK;
     }
     ctx->last_error = "internal: no solver layout";
@@ -1006,7 +1059,7 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         h->iter_parity ^= 1;
         hipEvent_t* ti = h->evi[h->iter_parity];
         h->built = false;                           // damping and the in-place factorisation consume it
-        if (h->use_sparse) { h->solver_damps = true; h->damp_radius = h->radius; }     // damping rides in the solver kernels
+        if (h->use_sparse || h->use_chain) { h->solver_damps = true; h->damp_radius = h->radius; }     // damping rides in the solver kernels
         else { rc = enqueue_damp(h, h->radius); if (rc) return rc; }
         const bool timing = ctx->timing && h->build_timed;
         if (timing) SFM_HIP_TRY(ctx, hipEventRecord(ti[0], st));
@@ -1353,6 +1406,7 @@ void sfmhip_ba_default_options(sfm_ba_options* o)
     o->fix_intrinsics = 0;
     o->verbose = 0;
     o->linearizer = 0;
+    o->solver = 0;
 }
 
 void sfmhip_ba_destroy(sfmhip_ba* h)

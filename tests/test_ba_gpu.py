@@ -501,3 +501,50 @@ def test_problem_memory_is_reused_across_solves_and_trim_releases_it(ctx):
         assert o[3] == outs[0][3] and o[4] == outs[0][4]
         for a, b in zip(o[:3], outs[0][:3]):
             assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# sfm_ba_options.solver = 0 on narrow bands (tracks of 2..4 frames: band 3 cameras): the chain solver of csrc/ba_chain.hpp
+# (fronts in LDS, a camera at a time, two launches) instead of the level-per-launch nested dissection (solver = 1)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,kw", [((16, 1500), dict()), ((30, 4000), dict(fix_intrinsics=1)), ((61, 9000), dict(fix_first_camera=0)),
+                                       ((120, 20000), dict(huber_delta=0.0)), ((200, 30000), dict())])
+def test_chain_solver_on_narrow_bands(ctx, shape, kw):
+    """Forced LM steps against the oracle (1e-8 on the cost, as for the other solver), against solver = 1 on the same problem
+    (two factorisations of one system in different orders: 1e-10 on the parameters), bit-identical reruns.  16 cameras: one
+    launch, one leaf per two waves; 200 cameras: 16 leaves, three tree levels in the second kernel."""
+    sc = synth.ba_scene(*shape, max_len=4)
+    runs = {}
+    for solver in (0, 0, 1):
+        pb = ctx.ba_create(*_args(sc), opts=ctx.ba_options(solver=solver, **kw))
+        s = pb.iterate(5)
+        runs.setdefault(solver, []).append((s, pb.params()))
+        pb.close()
+    so = orc.ba_solve(*_args(sc), force_iterations=5, opts=orc.ba_default_options(**kw))[3]
+    (s0, p0), (s0b, p0b) = runs[0]
+    (s1, p1), = runs[1]
+    assert s0["iterations"] == so["iterations"] == 5 and s0["successful_steps"] == so["successful_steps"]
+    assert abs(s0["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-11 * s1["final_cost"]
+    for x, y in zip(p0, p1):
+        assert _relerr(x, y) <= 1e-10
+    for x, y in zip(p0, p0b):
+        assert np.array_equal(x, y)
+
+
+def test_chain_solver_survives_a_failed_factorisation(ctx):
+    """A camera whose block of the damped system is not positive definite (a camera with two observations only, next to no damping):
+    the chain solver raises the error flag like the other solver, LM halves the radius and goes on instead of returning NaN."""
+    sc = synth.ba_scene(24, 2000, max_len=4)
+    keep = np.ones(len(sc["obs_cam"]), bool)
+    idx = np.nonzero(sc["obs_cam"] == 11)[0]
+    keep[idx[2:]] = False
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"][keep], sc["obs_pt"][keep], sc["obs_uv"][keep])
+    out = {}
+    for solver in (0, 1):
+        pb = ctx.ba_create(*args, opts=ctx.ba_options(solver=solver, initial_trust_region_radius=1e30, min_lm_diagonal=1e-300))
+        out[solver] = pb.iterate(6)
+        pb.close()
+    assert np.isfinite(out[0]["final_cost"]) and out[0]["final_cost"] <= out[0]["initial_cost"]
+    assert out[0]["successful_steps"] == out[1]["successful_steps"] < 6          # both solvers refuse the same steps
+    assert abs(out[0]["final_cost"] - out[1]["final_cost"]) <= 1e-6 * out[1]["final_cost"]
