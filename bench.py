@@ -431,8 +431,10 @@ def main():
             e2e["match_pairs_from_host"] = dict(ms=min(mruns[1:]), calls=[round(x, 3) for x in mruns], pairs=n_host - 1,
                                                 pairs_per_sec=(n_host - 1) / (min(mruns[1:]) * 1e-3), matches=int(sum(len(g) for g in got)),
                                                 host_bytes_uploaded=int(sum(c.nbytes for c in chain[:n_img_match])),
-                                                what="match_features_for_all on host descriptor matrices: per image upload (pinned staging) + preparation, "
-                                                     "one batched kNN-2 + ratio tail, match lists back on the host")
+                                                what="match_features_for_all on host descriptor matrices: ONE sfmhip_descsets_create_l2_host for the chain (the staging threads "
+                                                     "convert + verify the integer-valued float rows to bytes on their way into the pinned ring: 128 B per row over PCIe instead "
+                                                     "of 512; one preparation launch), one batched kNN-2 + ratio tail, match lists back on the host.  Host DRAM-read bound: "
+                                                     "5.1-8.3 ms from box to box (rounds 1-3: 16.8-22 ms)")
             if ham is not None:
                 hruns = []
                 for rep in range(3):

@@ -87,6 +87,15 @@ int sfmhip_descset_create_l2_host(sfmhip_ctx*, const float* desc, int rows, int 
 int sfmhip_descset_create_l2_dev (sfmhip_ctx*, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out);
 int sfmhip_descset_create_hamming2_host(sfmhip_ctx*, const uint8_t* desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
 int sfmhip_descset_create_hamming2_dev (sfmhip_ctx*, const uint8_t* d_desc, int rows, int nbytes, size_t ld, sfmhip_descset** out);
+/* Many images in one call: what match_features_for_all (NView:850-871, called on descriptor_for_all at NView:1369) hands over.
+ * desc[i]: rows[i] x dim on the host, row stride ld[i] elements (ld == NULL: dense).  One pass of the staging threads over all
+ * rows, one transfer stream, one preparation launch; out[0..n) receives the sets (all NULL again on error).
+ * L2: rows whose values are all integers in [0, 255] (cv::SIFT's) cross PCIe as BYTES -- the staging threads convert and verify on
+ *     the way into the pinned ring, 128 B per SIFT row instead of 512, and the device re-creates the float rows -- for dim 32 / 64 /
+ *     128; an image with any other value is uploaded as floats like sfmhip_descset_create_l2_host did in rounds 1-3.  Same sets,
+ *     same matches either way (tests/test_match_gpu.py). */
+int sfmhip_descsets_create_l2_host(sfmhip_ctx*, const float* const* desc, const int32_t* rows, int dim, const size_t* ld, int n, sfmhip_descset** out);
+int sfmhip_descsets_create_hamming2_host(sfmhip_ctx*, const uint8_t* const* desc, const int32_t* rows, int nbytes, const size_t* ld, int n, sfmhip_descset** out);
 void sfmhip_descset_destroy(sfmhip_descset*);
 /* re-run the device preparation pass (int8 copy + norms) on the set's float rows; enqueues only */
 int sfmhip_descset_refresh(sfmhip_descset*);

@@ -47,6 +47,7 @@ SYMBOLS = [
     "sfmhip_version", "sfmhip_set_kernel_timing", "sfmhip_match_kernel_ms",
     "sfmhip_descset_create_l2_host", "sfmhip_descset_create_l2_dev",
     "sfmhip_descset_create_hamming2_host", "sfmhip_descset_create_hamming2_dev",
+    "sfmhip_descsets_create_l2_host", "sfmhip_descsets_create_hamming2_host",
     "sfmhip_descset_destroy", "sfmhip_descset_refresh", "sfmhip_descsets_refresh", "sfmhip_descset_info",
     "sfmhip_knn2_dev", "sfmhip_knn2_l2_f32", "sfmhip_knn2_hamming2_u8", "sfmhip_ratio_filter",
     "sfmhip_match_features_l2", "sfmhip_match_features_hamming2",
@@ -94,6 +95,8 @@ def load():
         "sfmhip_descset_create_l2_dev": (i32, [vp, vp, i32, i32, sz, C.POINTER(vp)]),
         "sfmhip_descset_create_hamming2_host": (i32, [vp, vp, i32, i32, sz, C.POINTER(vp)]),
         "sfmhip_descset_create_hamming2_dev": (i32, [vp, vp, i32, i32, sz, C.POINTER(vp)]),
+        "sfmhip_descsets_create_l2_host": (i32, [vp, C.POINTER(vp), vp, i32, C.POINTER(sz), i32, C.POINTER(vp)]),
+        "sfmhip_descsets_create_hamming2_host": (i32, [vp, C.POINTER(vp), vp, i32, C.POINTER(sz), i32, C.POINTER(vp)]),
         "sfmhip_descset_destroy": (None, [vp]),
         "sfmhip_descset_refresh": (i32, [vp]),
         "sfmhip_descsets_refresh": (i32, [vp, C.POINTER(vp), i32]),

@@ -582,7 +582,7 @@ static int build_solver_plan(sfmhip_ba* h)
 
     // The chain solver (ba_chain.hpp) takes the natural layout (cameras in chain order, no padding inside).  It applies to bands of
     // at most CH_WMAX = 3 cameras (tracks of up to four frames): its fronts then have <= 59 rows, one lane each.  Measured in the LM
-    // loop on such scenes (experiments/_chk_chain.py, MI355X): reduced solve 0.094 against 0.128 ms at 200 cameras, 0.071 against
+    // loop on such scenes (experiments/chain_vs_levels.py, MI355X): reduced solve 0.094 against 0.128 ms at 200 cameras, 0.071 against
     // 0.084 ms at 50, 0.044 against 0.047 ms at 24, 0.025 against 0.022 ms at 8 -- hence from 12 free cameras on.  Beyond ~640 cameras
     // its leaves get long (32 leaves at most, two waves each) and the level-per-launch solver, whose leaves are throughput-bound
     // panels, is level with it again (999 cameras: 242 us against 238 us).  SURVEY 8d's scenes (tracks of 2..6 frames: band 5) stay

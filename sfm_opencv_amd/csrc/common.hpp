@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -150,6 +151,12 @@ static inline int sfm_pinned(sfmhip_ctx* ctx, size_t bytes, void** out)
 // 9-13 GB/s on the MI355X boxes (one runtime thread staging); this goes through two pinned 16 MB buffers filled by four host
 // threads instead (43 GB/s, experiments/h2d_bench.hip).  The source has been consumed when the call returns.
 int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+// the same, but every pinned piece is PRODUCED on the copy threads on its way into the staging ring (a conversion, a gather of strided
+// rows): fill(piece, off, n, t, nt) writes thread t's share of the bytes [off, off + n) of the transfer to piece[0 .. n); pieces are
+// multiples of `granule` bytes except the last.  Everything fill reads has been consumed when the call returns.
+int sfm_upload_produced(sfmhip_ctx* ctx, void* dst, size_t bytes, size_t granule, const std::function<void(char*, size_t, size_t, int, int)>& fill);
+// f(t, nt) on every copy thread of the context, the caller included
+void sfm_parallel(sfmhip_ctx* ctx, const std::function<void(int, int)>& f);
 
 // device block of at least `bytes` from the context's cache (an idle block of up to 4x the size, else a new hipMalloc); stream-ordered
 // reuse: every user of these blocks works on the context's stream

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 
 SfmRoctx::SfmRoctx()
 {
@@ -18,27 +19,35 @@ SfmRoctx::SfmRoctx()
     }
 }
 
-// Helper threads of sfm_upload: they sleep on a condition variable and each copies one slice of the current piece.
+// Helper threads of sfm_upload / sfm_upload_produced: they sleep on a condition variable and each runs its share of the current job.
+// As many as the cores this process may use, between 4 and 16 (the caller is one of them): a memcpy into the staging ring reaches
+// 43 GB/s with four, and a float -> byte conversion on the way in is bound by the DRAM read rate of as many as there are.
 struct CopyPool {
-    static constexpr int NT = 4;               // the caller + three helpers
-    std::thread th[NT - 1];
+    int NT;
+    std::vector<std::thread> th;
     std::mutex mu; std::condition_variable cv_go, cv_done;
     unsigned long long gen = 0; int pending = 0; bool quit = false;
-    const char* src = nullptr; char* dst = nullptr; size_t n = 0;
-    static void slice(const char* s, char* d, size_t n, int t) { const size_t a = n * t / NT, e = n * (t + 1) / NT; memcpy(d + a, s + a, e - a); }
-    CopyPool()
+    const std::function<void(int, int)>* job = nullptr;
+    static int pick_threads()
+    {
+        int cores = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cores = CPU_COUNT(&set);
+        return std::min(16, std::max(4, cores));
+    }
+    CopyPool() : NT(pick_threads())
     {
         for (int t = 1; t < NT; ++t)
-            th[t - 1] = std::thread([this, t] {
+            th.emplace_back([this, t] {
                 unsigned long long seen = 0;
                 for (;;) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv_go.wait(lk, [&] { return quit || gen != seen; });
                     if (quit) return;
                     seen = gen;
-                    const char* s = src; char* d = dst; const size_t cnt = n;
+                    const std::function<void(int, int)>* f = job;
                     lk.unlock();
-                    slice(s, d, cnt, t);
+                    (*f)(t, NT);
                     lk.lock();
                     if (--pending == 0) cv_done.notify_one();
                 }
@@ -50,37 +59,57 @@ struct CopyPool {
         cv_go.notify_all();
         for (auto& t : th) t.join();
     }
-    void copy(const char* s, char* d, size_t cnt)
+    void run(const std::function<void(int, int)>& f)
     {
-        { std::lock_guard<std::mutex> lk(mu); src = s; dst = d; n = cnt; pending = NT - 1; ++gen; }
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = NT - 1; ++gen; }
         cv_go.notify_all();
-        slice(s, d, cnt, 0);
+        f(0, NT);
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
 
-int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes)
+void sfm_parallel(sfmhip_ctx* ctx, const std::function<void(int, int)>& f)
 {
-    if (bytes == 0) return SFMHIP_OK;
-    const size_t CH = sfmhip_ctx::STAGE_BYTES;
+    if (!ctx->copy_pool) ctx->copy_pool = new CopyPool();
+    ctx->copy_pool->run(f);
+}
+
+static int stage_ring(sfmhip_ctx* ctx)
+{
     for (int b = 0; b < 2; ++b)
         if (!ctx->stage[b]) {
-            SFM_HIP_TRY(ctx, hipHostMalloc(&ctx->stage[b], CH, hipHostMallocDefault));
+            SFM_HIP_TRY(ctx, hipHostMalloc(&ctx->stage[b], sfmhip_ctx::STAGE_BYTES, hipHostMallocDefault));
             SFM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
         }
-    if (bytes >= ((size_t)1 << 20) && !ctx->copy_pool) ctx->copy_pool = new CopyPool();
+    return SFMHIP_OK;
+}
+
+int sfm_upload_produced(sfmhip_ctx* ctx, void* dst, size_t bytes, size_t granule, const std::function<void(char*, size_t, size_t, int, int)>& fill)
+{
+    if (bytes == 0) return SFMHIP_OK;
+    { const int rc = stage_ring(ctx); if (rc) return rc; }
+    const size_t CH = granule > 0 && granule <= sfmhip_ctx::STAGE_BYTES ? sfmhip_ctx::STAGE_BYTES / granule * granule : sfmhip_ctx::STAGE_BYTES;
     for (size_t off = 0; off < bytes; off += CH) {
         const size_t n = std::min(CH, bytes - off);
         const int b = ctx->stage_next;
         if (ctx->stage_busy[b]) SFM_HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[b]));
-        const char* s = (const char*)src + off; char* d = (char*)ctx->stage[b];
-        if (n >= ((size_t)1 << 20)) ctx->copy_pool->copy(s, d, n); else memcpy(d, s, n);
+        char* d = (char*)ctx->stage[b];
+        if (n >= ((size_t)256 << 10)) sfm_parallel(ctx, [&](int t, int nt) { fill(d, off, n, t, nt); });
+        else fill(d, off, n, 0, 1);
         SFM_HIP_TRY(ctx, hipMemcpyAsync((char*)dst + off, d, n, hipMemcpyHostToDevice, ctx->stream));
         SFM_HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[b], ctx->stream));
         ctx->stage_busy[b] = true; ctx->stage_next = b ^ 1;
     }
     return SFMHIP_OK;
+}
+
+int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    return sfm_upload_produced(ctx, dst, bytes, 64, [src](char* piece, size_t off, size_t n, int t, int nt) {
+        const size_t a = n * t / nt, e = n * (t + 1) / nt;
+        memcpy(piece + a, (const char*)src + off + a, e - a);
+    });
 }
 
 int sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out)

@@ -16,6 +16,8 @@
 #pragma clang fp contract(off)
 #include <cfloat>
 #include <climits>
+#include <algorithm>
+#include <emmintrin.h>
 #include <type_traits>
 
 #define KNN_BLOCK_ROWS 256     // descriptor sets are padded to a multiple of this (chunks of the kNN kernels are whole multiples)
@@ -143,16 +145,53 @@ __global__ void prep_l2_batched_kernel(const PrepDesc* __restrict__ tbl, int fas
     else prep_l2_rows(src, d.ld, d.rows, d.dim, d.dim_pad, d.rows_pad, dst, norm, d.flag, wave_index);
 }
 
+// Rows that crossed PCIe as BYTES (sfmhip_descsets_create_l2_host: the staging threads convert integer-valued float rows on their way
+// into the pinned ring, 128 B per SIFT row instead of 512): the biased int8 copy, the two norm terms and the float rows the exact
+// kernels read (re-scoring of square-root collisions), one launch for all images.  16 values per lane, dim in {32, 64, 128}.
+struct PrepU8Desc { const uint8_t* src; int rows, dim, rows_pad; int8_t* dst; int32_t* norm; float* f32; };
+__global__ void prep_l2_u8_batched_kernel(const PrepU8Desc* __restrict__ tbl)
+{
+    const PrepU8Desc d = tbl[blockIdx.y];
+    const uint8_t* src = (const uint8_t*)(const uint8_t __attribute__((address_space(1)))*)(uintptr_t)d.src;
+    int8_t* dst = (int8_t*)(int8_t __attribute__((address_space(1)))*)(uintptr_t)d.dst;
+    int32_t* norm = (int32_t*)(int32_t __attribute__((address_space(1)))*)(uintptr_t)d.norm;
+    float* f32 = (float*)(float __attribute__((address_space(1)))*)(uintptr_t)d.f32;
+    const int lane = threadIdx.x & 63, wave_index = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lpr = d.dim >> 4;                         // lanes per row: 2, 4 or 8
+    const int row = wave_index * (64 / lpr) + lane / lpr, k = (lane % lpr) * 16;
+    if (row >= d.rows_pad) return;
+    int acc = 0, sum = 0;
+    v4i packed = { 0, 0, 0, 0 };
+    if (row < d.rows) {
+        const v4i u = *(const v4i*)(src + (size_t)row * d.dim + k);
+        float4* fo = (float4*)(f32 + (size_t)row * d.dim + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned w = (unsigned)u[j];
+            fo[j] = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+            const int q = (int)(w ^ 0x80808080u);
+            packed[j] = q;
+            acc = __builtin_amdgcn_sdot4(q, q, acc, false);
+            sum = __builtin_amdgcn_sdot4(q, 0x01010101, sum, false);
+        }
+    }
+    *(v4i*)(dst + (size_t)row * d.dim + k) = packed;
+    for (int off = lpr >> 1; off > 0; off >>= 1) { acc += __shfl_xor(acc, off); sum += __shfl_xor(sum, off); }
+    if (lane % lpr == 0) {
+        norm[row] = row < d.rows ? acc : PAD_NORM;
+        norm[d.rows_pad + row] = row < d.rows ? acc + 2 * sum : PAD_NORM;
+    }
+}
+
 // Hamming2: rows into 64-byte zero-padded rows, re-encoded so that one dword carries 32 two-bit cells' LOW bits and
 // another their HIGH bits: with a[0..15] the 16 dwords of a row and M = 0x55555555,
 //     L[i] = (a[2i] & M) | ((a[2i+1] & M) << 1),   H[i] = ((a[2i] >> 1) & M) | (a[2i+1] & ~M),   i = 0..7
 // (cells of a[2i] on the even bit positions, cells of a[2i+1] on the odd ones).  A cell differs iff its low bits or its
 // high bits differ, so NORM_HAMMING2(a, b) = sum_i popcount((La[i]^Lb[i]) | (Ha[i]^Hb[i])): 3 VALU ops per 32 cells
 // (v_xor, v_bitop3, v_bcnt) instead of 5 per 16.  Stored as [L0..L7 | H0..H7].
-__global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
-                                    uint32_t* __restrict__ dst, int rows_pad)
+__device__ __forceinline__ void prep_hamming_body(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                                  uint32_t* __restrict__ dst, int rows_pad, size_t i)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows_pad * 8) return;
     const int row = (int)(i >> 3), k = (int)(i & 7);
     uint32_t a0 = 0, a1 = 0;
@@ -167,6 +206,19 @@ __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, 
     const uint32_t M = 0x55555555u;
     dst[(size_t)row * 16 + k] = (a0 & M) | ((a1 & M) << 1);
     dst[(size_t)row * 16 + 8 + k] = ((a0 >> 1) & M) | (a1 & ~M);
+}
+__global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                    uint32_t* __restrict__ dst, int rows_pad)
+{
+    prep_hamming_body(src, ld, rows, nbytes, dst, rows_pad, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// one launch for many images (blockIdx.y = image): sfmhip_descsets_create_hamming2_host
+struct PrepHamDesc { const uint8_t* src; size_t ld; int rows, nbytes, rows_pad; uint32_t* u32; uint32_t* f4; };
+__global__ void prep_hamming_batched_kernel(const PrepHamDesc* __restrict__ tbl)
+{
+    const PrepHamDesc d = tbl[blockIdx.y];
+    prep_hamming_body((const uint8_t*)(const uint8_t __attribute__((address_space(1)))*)(uintptr_t)d.src, d.ld, d.rows, d.nbytes,
+                      (uint32_t*)(uint32_t __attribute__((address_space(1)))*)(uintptr_t)d.u32, d.rows_pad, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Hamming2 on the matrix cores: every row as 768 FP4 (e2m1) values = 24 blocks of 32 = 384 bytes.  A two-bit cell (b0, b1) becomes
@@ -183,10 +235,9 @@ __global__ void prep_hamming_kernel(const uint8_t* __restrict__ src, size_t ld, 
 #define H4_WAVES 8             // waves per workgroup of knn2_hamming2_fp4_kernel (4 or 8)
 #endif
 #define H4_MAX_NBYTES 61
-__global__ void prep_hamming_fp4_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
-                                        uint32_t* __restrict__ dst, int rows_pad)
+__device__ __forceinline__ void prep_hamming_fp4_body(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                                      uint32_t* __restrict__ dst, int rows_pad, size_t i)     // i: one dword = 8 values
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one dword = 8 values
     if (i >= (size_t)rows_pad * 96) return;
     const int row = (int)(i / 96), w = (int)(i % 96);
     const bool pad = row >= rows;
@@ -214,6 +265,18 @@ __global__ void prep_hamming_fp4_kernel(const uint8_t* __restrict__ src, size_t 
         out |= code << (4 * n);
     }
     dst[i] = out;
+}
+__global__ void prep_hamming_fp4_kernel(const uint8_t* __restrict__ src, size_t ld, int rows, int nbytes,
+                                        uint32_t* __restrict__ dst, int rows_pad)
+{
+    prep_hamming_fp4_body(src, ld, rows, nbytes, dst, rows_pad, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void prep_hamming_fp4_batched_kernel(const PrepHamDesc* __restrict__ tbl)
+{
+    const PrepHamDesc d = tbl[blockIdx.y];
+    if (!d.f4) return;
+    prep_hamming_fp4_body((const uint8_t*)(const uint8_t __attribute__((address_space(1)))*)(uintptr_t)d.src, d.ld, d.rows, d.nbytes,
+                          (uint32_t*)(uint32_t __attribute__((address_space(1)))*)(uintptr_t)d.f4, d.rows_pad, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1212,7 +1275,171 @@ static int descset_prepare_l2(sfmhip_ctx* ctx, sfmhip_descset* s)
     return SFMHIP_OK;
 }
 
+// dim floats -> dim bytes; false when a value is not an integer in [0, 255] (NaN included).  SSE2: what every x86-64 has.
+static inline bool l2_row_to_u8(const float* __restrict__ src, uint8_t* __restrict__ dst, int dim)
+{
+    int k = 0;
+    __m128i bad = _mm_setzero_si128();
+    for (; k + 16 <= dim; k += 16) {
+        const __m128 a0 = _mm_loadu_ps(src + k), a1 = _mm_loadu_ps(src + k + 4), a2 = _mm_loadu_ps(src + k + 8), a3 = _mm_loadu_ps(src + k + 12);
+        const __m128i i0 = _mm_cvtps_epi32(a0), i1 = _mm_cvtps_epi32(a1), i2 = _mm_cvtps_epi32(a2), i3 = _mm_cvtps_epi32(a3);
+        // out of [0, 255] (NaN converts to 0x80000000) or not an integer
+        const __m128i range = _mm_or_si128(_mm_or_si128(i0, i1), _mm_or_si128(i2, i3));
+        const __m128 ne = _mm_or_ps(_mm_or_ps(_mm_cmpneq_ps(_mm_cvtepi32_ps(i0), a0), _mm_cmpneq_ps(_mm_cvtepi32_ps(i1), a1)),
+                                    _mm_or_ps(_mm_cmpneq_ps(_mm_cvtepi32_ps(i2), a2), _mm_cmpneq_ps(_mm_cvtepi32_ps(i3), a3)));
+        bad = _mm_or_si128(bad, _mm_or_si128(_mm_andnot_si128(_mm_set1_epi32(255), range), _mm_castps_si128(ne)));
+        _mm_storeu_si128((__m128i*)(dst + k), _mm_packus_epi16(_mm_packs_epi32(i0, i1), _mm_packs_epi32(i2, i3)));
+    }
+    bool ok = _mm_movemask_epi8(_mm_cmpeq_epi32(bad, _mm_setzero_si128())) == 0xffff;
+    for (; k < dim; ++k) {
+        const float v = src[k];
+        const int q = (v >= 0.0f && v <= 255.0f) ? (int)v : -1;
+        if (q < 0 || (float)q != v) { ok = false; dst[k] = 0; } else dst[k] = (uint8_t)q;
+    }
+    return ok;
+}
+
+static int descset_create_l2_host_f32(sfmhip_ctx* ctx, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out);
+static void descsets_destroy_all(sfmhip_descset** out, int n)
+{
+    for (int i = 0; i < n; ++i) if (out[i]) { sfmhip_descset_destroy(out[i]); out[i] = nullptr; }
+}
+
 extern "C" {
+
+// Many images from host matrices in one call (the chain of match_features_for_all, NViewReconstuct.cpp:850-871 / :1369):
+// one pass of the staging threads over all rows, one transfer stream, one preparation launch.  Integer-valued rows in [0, 255]
+// (what cv::SIFT emits) cross PCIe as bytes: a quarter of the float rows' size; an image with any other value goes the
+// float way of sfmhip_descset_create_l2_host (and takes the exact kernels later), image by image.
+int sfmhip_descsets_create_l2_host(sfmhip_ctx* ctx, const float* const* desc, const int32_t* rows, int dim, const size_t* ld, int n, sfmhip_descset** out)
+{
+    SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_descsets_create_l2_host");
+    SFM_ARG_CHECK(ctx, ctx && out && (n == 0 || (desc && rows)) && n >= 0 && dim > 0);
+    for (int i = 0; i < n; ++i) { out[i] = nullptr; SFM_ARG_CHECK(ctx, rows[i] >= 0 && (desc[i] || rows[i] == 0) && (!ld || ld[i] >= (size_t)dim)); }
+    if (n == 0) return SFMHIP_OK;
+    const bool bytes_ok = dim == 32 || dim == 64 || dim == 128;        // the int8 copy has no padding columns and a lane takes 16 values
+    if (!bytes_ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = descset_create_l2_host_f32(ctx, desc[i], rows[i], dim, ld ? ld[i] : (size_t)dim, &out[i]);
+            if (rc) { descsets_destroy_all(out, n); return rc; }
+        }
+        return SFMHIP_OK;
+    }
+    std::vector<long long> first((size_t)n + 1, 0);                   // first row of image i in the concatenation of all images
+    for (int i = 0; i < n; ++i) first[i + 1] = first[i] + rows[i];
+    const long long total = first[n];
+    uint8_t* d_u8 = nullptr;
+    { void* q = nullptr; int rc = sfm_pool_get(ctx, (size_t)std::max<long long>(total, 1) * dim, &q); if (rc) return rc; d_u8 = (uint8_t*)q; }
+    std::vector<int> bad((size_t)n, 0);
+    int rc = sfm_upload_produced(ctx, d_u8, (size_t)total * dim, (size_t)dim, [&](char* piece, size_t off, size_t nb, int t, int nt) {
+        const long long g0 = (long long)(off / dim), cnt = (long long)(nb / dim);
+        long long r = g0 + cnt * t / nt;
+        const long long re = g0 + cnt * (t + 1) / nt;
+        int img = (int)(std::upper_bound(first.begin(), first.end(), r) - first.begin()) - 1;
+        for (; r < re; ++r) {
+            while (r >= first[img + 1]) ++img;
+            const float* src = desc[img] + (size_t)(r - first[img]) * (ld ? ld[img] : (size_t)dim);
+            if (!l2_row_to_u8(src, (uint8_t*)piece + (size_t)(r - g0) * dim, dim)) __atomic_store_n(&bad[img], 1, __ATOMIC_RELAXED);
+        }
+    });
+    if (rc) { sfm_pool_put(ctx, d_u8); return rc; }
+    std::vector<PrepU8Desc> tbl;
+    int max_pad = 0;
+    for (int i = 0; i < n && rc == SFMHIP_OK; ++i) {
+        if (bad[i]) { rc = descset_create_l2_host_f32(ctx, desc[i], rows[i], dim, ld ? ld[i] : (size_t)dim, &out[i]); continue; }
+        sfmhip_descset* s = nullptr;
+        descset_alloc_common(ctx, SFMHIP_DESC_L2_F32, rows[i], dim, &s);
+        out[i] = s;
+        s->dim_pad = dim; s->ld = dim; s->owns_f32 = true; s->exact_u8 = 1; s->exact_pending = false;
+        void* q = nullptr;
+        rc = sfm_pool_get(ctx, (size_t)std::max(rows[i], 1) * dim * sizeof(float), &q); if (rc) break; s->d_f32 = (float*)q;
+        rc = sfm_pool_get(ctx, (size_t)s->rows_pad * dim, &q); if (rc) break; s->d_i8 = (int8_t*)q;
+        rc = sfm_pool_get(ctx, 2 * (size_t)s->rows_pad * sizeof(int32_t), &q); if (rc) break; s->d_norm = (int32_t*)q;
+        rc = descset_flag_slot(ctx, s); if (rc) break;          // (sfmhip_descset_refresh re-derives the verdict there)
+        PrepU8Desc d; d.src = d_u8 + (size_t)first[i] * dim; d.rows = rows[i]; d.dim = dim; d.rows_pad = s->rows_pad; d.dst = s->d_i8; d.norm = s->d_norm; d.f32 = (float*)s->d_f32;
+        tbl.push_back(d);
+        max_pad = std::max(max_pad, s->rows_pad);
+    }
+    if (rc == SFMHIP_OK && !tbl.empty()) {
+        void* d_tbl = nullptr;
+        rc = sfm_scratch2(ctx, tbl.size() * sizeof(PrepU8Desc), &d_tbl);
+        if (rc == SFMHIP_OK) {
+            hipError_t e = sfm_upload(ctx, d_tbl, tbl.data(), tbl.size() * sizeof(PrepU8Desc)) == SFMHIP_OK ? hipSuccess : hipErrorUnknown;     // (consumed on return)
+            if (e == hipSuccess) {
+                const int rows_per_block = 4 * (1024 / dim);
+                hipLaunchKernelGGL(prep_l2_u8_batched_kernel, dim3(ceil_div(max_pad, rows_per_block), (unsigned)tbl.size()), dim3(256), 0, ctx->stream, (const PrepU8Desc*)d_tbl);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
+        }
+    }
+    sfm_pool_put(ctx, d_u8);          // read only by the launch just enqueued (stream-ordered reuse)
+    if (rc) descsets_destroy_all(out, n);
+    return rc;
+}
+
+// The Hamming2 twin: all images' byte rows in one transfer, their two re-encodings in two launches (one each) instead of two per image.
+int sfmhip_descsets_create_hamming2_host(sfmhip_ctx* ctx, const uint8_t* const* desc, const int32_t* rows, int nbytes, const size_t* ld, int n, sfmhip_descset** out)
+{
+    SFM_DEVICE_GUARD(ctx);
+    SFM_RANGE("sfmhip_descsets_create_hamming2_host");
+    SFM_ARG_CHECK(ctx, ctx && out && (n == 0 || (desc && rows)) && n >= 0 && nbytes > 0 && nbytes <= 64);
+    for (int i = 0; i < n; ++i) { out[i] = nullptr; SFM_ARG_CHECK(ctx, rows[i] >= 0 && (desc[i] || rows[i] == 0) && (!ld || ld[i] >= (size_t)nbytes)); }
+    if (n == 0) return SFMHIP_OK;
+    std::vector<long long> first((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) first[i + 1] = first[i] + rows[i];
+    const long long total = first[n];
+    uint8_t* d_u8 = nullptr;
+    { void* q = nullptr; int rc = sfm_pool_get(ctx, (size_t)std::max<long long>(total, 1) * nbytes, &q); if (rc) return rc; d_u8 = (uint8_t*)q; }
+    int rc = sfm_upload_produced(ctx, d_u8, (size_t)total * nbytes, (size_t)nbytes, [&](char* piece, size_t off, size_t nb, int t, int nt) {
+        const long long g0 = (long long)(off / nbytes), cnt = (long long)(nb / nbytes);
+        long long r = g0 + cnt * t / nt;
+        const long long re = g0 + cnt * (t + 1) / nt;
+        int img = (int)(std::upper_bound(first.begin(), first.end(), r) - first.begin()) - 1;
+        while (r < re) {
+            while (r >= first[img + 1]) ++img;
+            const long long run = std::min(re, first[img + 1]) - r;          // rows of this image in the share
+            const size_t l = ld ? ld[img] : (size_t)nbytes;
+            const uint8_t* src = desc[img] + (size_t)(r - first[img]) * l;
+            uint8_t* dst = (uint8_t*)piece + (size_t)(r - g0) * nbytes;
+            if (l == (size_t)nbytes) memcpy(dst, src, (size_t)run * nbytes);
+            else for (long long k = 0; k < run; ++k) memcpy(dst + (size_t)k * nbytes, src + (size_t)k * l, (size_t)nbytes);
+            r += run;
+        }
+    });
+    if (rc) { sfm_pool_put(ctx, d_u8); return rc; }
+    std::vector<PrepHamDesc> tbl((size_t)n);
+    int max_pad = 0; bool any_f4 = false;
+    for (int i = 0; i < n && rc == SFMHIP_OK; ++i) {
+        sfmhip_descset* s = nullptr;
+        descset_alloc_common(ctx, SFMHIP_DESC_HAMMING2_U8, rows[i], nbytes, &s);
+        out[i] = s;
+        void* q = nullptr;
+        rc = sfm_pool_get(ctx, (size_t)s->rows_pad * 64, &q); if (rc) break; s->d_u32 = (uint32_t*)q;
+        if (nbytes <= H4_MAX_NBYTES) { rc = sfm_pool_get(ctx, (size_t)s->rows_pad * H4_ROW_BYTES, &q); if (rc) break; s->d_f4 = (uint32_t*)q; any_f4 = true; }
+        PrepHamDesc& d = tbl[i];
+        d.src = d_u8 + (size_t)first[i] * nbytes; d.ld = (size_t)nbytes; d.rows = rows[i]; d.nbytes = nbytes; d.rows_pad = s->rows_pad; d.u32 = s->d_u32; d.f4 = s->d_f4;
+        max_pad = std::max(max_pad, s->rows_pad);
+    }
+    if (rc == SFMHIP_OK) {
+        void* d_tbl = nullptr;
+        rc = sfm_scratch2(ctx, tbl.size() * sizeof(PrepHamDesc), &d_tbl);
+        if (rc == SFMHIP_OK) {
+            hipError_t e = sfm_upload(ctx, d_tbl, tbl.data(), tbl.size() * sizeof(PrepHamDesc)) == SFMHIP_OK ? hipSuccess : hipErrorUnknown;
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(prep_hamming_batched_kernel, dim3((unsigned)(((size_t)max_pad * 8 + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, (const PrepHamDesc*)d_tbl);
+                if (any_f4)
+                    hipLaunchKernelGGL(prep_hamming_fp4_batched_kernel, dim3((unsigned)(((size_t)max_pad * 96 + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, (const PrepHamDesc*)d_tbl);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = SFMHIP_E_HIP; }
+        }
+    }
+    sfm_pool_put(ctx, d_u8);
+    if (rc) descsets_destroy_all(out, n);
+    return rc;
+}
 
 int sfmhip_descset_create_l2_dev(sfmhip_ctx* ctx, const float* d_desc, int rows, int dim, size_t ld, sfmhip_descset** out)
 {
@@ -1233,6 +1460,15 @@ int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, 
     SFM_DEVICE_GUARD(ctx);
     SFM_ARG_CHECK(ctx, ctx && out);
     SFM_ARG_CHECK(ctx, (desc || rows == 0) && rows >= 0 && dim > 0 && ld >= (size_t)dim);
+    // integer-valued rows cross PCIe as bytes (sfmhip_descsets_create_l2_host); anything else as floats (below)
+    if (dim == 32 || dim == 64 || dim == 128) return sfmhip_descsets_create_l2_host(ctx, &desc, &rows, dim, &ld, 1, out);
+    return descset_create_l2_host_f32(ctx, desc, rows, dim, ld, out);
+}
+
+}  // extern "C"
+
+static int descset_create_l2_host_f32(sfmhip_ctx* ctx, const float* desc, int rows, int dim, size_t ld, sfmhip_descset** out)
+{
     float* d = nullptr;
     const size_t nrow = rows > 0 ? rows : 1;
     { void* q = nullptr; int rc = sfm_pool_get(ctx, nrow * dim * sizeof(float), &q); if (rc) return rc; d = (float*)q; }
@@ -1253,6 +1489,8 @@ int sfmhip_descset_create_l2_host(sfmhip_ctx* ctx, const float* desc, int rows, 
     *out = s;
     return SFMHIP_OK;
 }
+
+extern "C" {
 
 static int descset_prepare_hamming(sfmhip_ctx* ctx, sfmhip_descset* s, const uint8_t* d_src, size_t ld)
 {

@@ -109,11 +109,32 @@ inline void match_features_for_all(const std::vector<Mat>& descriptor_for_all, s
     if (!ctx || n < 2) return;
     std::vector<sfmhip_descset*> sets((size_t)n, nullptr);
     int max_rows = 1, rc = SFMHIP_OK;
-    for (int i = 0; i < n && rc == SFMHIP_OK; ++i) {
+    // all images in one call (one pass of the staging threads, one transfer stream, one preparation launch) when they share a type
+    // and a row length -- what extract_features produces; image by image otherwise
+    bool uniform = true;
+    for (int i = 0; i < n; ++i) {
         const Mat& d = descriptor_for_all[i];
         max_rows = d.rows > max_rows ? d.rows : max_rows;
-        rc = d.type == CV_8U ? sfmhip_descset_create_hamming2_host(ctx, d.ptr<uint8_t>(), d.rows, d.cols, (size_t)d.cols, &sets[i])
-                             : sfmhip_descset_create_l2_host(ctx, d.ptr<float>(), d.rows, d.cols, (size_t)d.cols, &sets[i]);
+        uniform = uniform && d.type == descriptor_for_all[0].type && d.cols == descriptor_for_all[0].cols && d.cols > 0;
+    }
+    if (uniform) {
+        std::vector<int32_t> rows((size_t)n);
+        for (int i = 0; i < n; ++i) rows[i] = descriptor_for_all[i].rows;
+        if (descriptor_for_all[0].type == CV_8U) {
+            std::vector<const uint8_t*> ptrs((size_t)n);
+            for (int i = 0; i < n; ++i) ptrs[i] = descriptor_for_all[i].ptr<uint8_t>();
+            rc = sfmhip_descsets_create_hamming2_host(ctx, ptrs.data(), rows.data(), descriptor_for_all[0].cols, nullptr, n, sets.data());
+        } else {
+            std::vector<const float*> ptrs((size_t)n);
+            for (int i = 0; i < n; ++i) ptrs[i] = descriptor_for_all[i].ptr<float>();
+            rc = sfmhip_descsets_create_l2_host(ctx, ptrs.data(), rows.data(), descriptor_for_all[0].cols, nullptr, n, sets.data());
+        }
+    } else {
+        for (int i = 0; i < n && rc == SFMHIP_OK; ++i) {
+            const Mat& d = descriptor_for_all[i];
+            rc = d.type == CV_8U ? sfmhip_descset_create_hamming2_host(ctx, d.ptr<uint8_t>(), d.rows, d.cols, (size_t)d.cols, &sets[i])
+                                 : sfmhip_descset_create_l2_host(ctx, d.ptr<float>(), d.rows, d.cols, (size_t)d.cols, &sets[i]);
+        }
     }
     std::vector<int32_t> pairs, counts((size_t)n - 1, 0);
     for (int i = 0; i + 1 < n; ++i) { printf("Matching images %d - %d\n", i, i + 1); pairs.push_back(i); pairs.push_back(i + 1); }

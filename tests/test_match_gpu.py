@@ -294,3 +294,45 @@ def test_host_entry_points_strided_rows_large_uploads_and_block_reuse(ctx):
     assert np.array_equal(g, orc.match_features_l2(mixed[0], mixed[1]))
     b = synth.akaze_descriptor_chain(2, 5000, seed=5)
     assert np.array_equal(api.match_features_for_all(b, ctx=ctx)[0], orc.match_features_hamming2(b[0], b[1]))
+
+
+# ------------------------------------------------------------------------------------------------
+# many images from host matrices in one call (sfmhip_descsets_create_{l2,hamming2}_host): integer-valued L2 rows cross
+# PCIe as bytes, every other image as floats; the sets must be the ones the per-image calls build
+# ------------------------------------------------------------------------------------------------
+def test_batched_host_sets_match_like_per_image_sets(ctx):
+    rng = np.random.default_rng(11)
+    chain = synth.sift_descriptor_chain(6, 700, seed=3)
+    chain = [c.copy() for c in chain]
+    chain[2] = chain[2][:333]                                     # ragged
+    chain[3][5, 7] += 0.25                                        # one non-integer value: this image goes the float way (exact kernels)
+    chain[4] = np.ascontiguousarray(np.pad(chain[4], ((0, 0), (0, 16))))[:, :128]        # strided rows (ld = 144)
+    assert chain[4].strides[0] == 144 * 4
+    pairs = np.stack([np.arange(5), np.arange(1, 6)], 1)
+    batch = ctx.descsets_host(chain)
+    infos = [s.info() for s in batch]
+    assert [i["exact_u8"] for i in infos] == [True, True, True, False, True, True] and infos[2]["rows"] == 333
+    single = [ctx.descset_l2(np.ascontiguousarray(c)) for c in chain]
+    got = ctx.match_pairs(batch, pairs); want = ctx.match_pairs(single, pairs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        ref = orc.match_features_l2(np.ascontiguousarray(chain[i]), np.ascontiguousarray(chain[i + 1]))
+        assert len(ref) > 20 and np.array_equal(g, w) and np.array_equal(g, ref), i
+    # the float rows re-created on the device are the caller's: the exact kernel on them gives the same neighbours
+    import torch
+    idx = torch.empty((700, 2), dtype=torch.int32, device="cuda"); dist = torch.empty((700, 2), dtype=torch.float32, device="cuda")
+    ctx.knn2_dev(batch[0], batch[1], idx, dist, force_path=2)
+    oi, od = orc.knn2_l2(chain[0], chain[1])
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    # values outside [0, 255], NaN, negative zero
+    odd = [rng.integers(0, 256, (40, 128)).astype(np.float32) for _ in range(4)]
+    odd[0][3, 3] = 256.0; odd[1][0, 0] = -1.0; odd[2][39, 127] = np.nan; odd[3][1, 1] = -0.0
+    sets = ctx.descsets_host(odd)
+    assert [s.info()["exact_u8"] for s in sets] == [False, False, False, True]
+    # Hamming2
+    hchain = [rng.integers(0, 256, (r, 61), dtype=np.uint8) for r in (300, 517, 64, 1)]
+    hb = ctx.descsets_host(hchain); hs = [ctx.descset_hamming2(c) for c in hchain]
+    hp = np.array([[0, 1], [1, 2], [2, 3], [3, 0]])
+    for g, w in zip(ctx.match_pairs(hb, hp, ratio=0.97), ctx.match_pairs(hs, hp, ratio=0.97)):
+        assert np.array_equal(g, w)
+    assert ctx.descsets_host([]) == []
