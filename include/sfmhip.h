@@ -271,12 +271,27 @@ int  sfmhip_rccl_comm_destroy(void* comm);
 int  sfmhip_ba_set_rccl(sfmhip_ba*, void* comm, int rank, int world);
 int  sfmhip_rccl_allreduce_f64(sfmhip_ctx*, void* comm, void* d_buf, size_t count);
 /* bundle_adjustment (NView:1162-1244) on several GPUs of ONE process -- what a C++ caller like the reference's main() uses: one context per
- * device, same arguments and in-place semantics as sfmhip_ba_solve.  The points are sharded by first camera over the contexts, one host
- * thread per context builds and runs its shard, the reduced-system message is summed by RCCL; where two contexts share a device (one-card
- * rehearsal) or librccl is missing, by a host-staged exchange inside the process.  n_ctx = 1 is sfmhip_ba_solve. */
+ * device, same arguments and in-place semantics as sfmhip_ba_solve.  The points are sharded by the first camera that sees them (the cameras
+ * cut into n_ctx consecutive ranges of equal observation count; a few parallel passes on the host), one host thread per context builds and
+ * runs its shard, the reduced-system message is summed by RCCL; where two contexts share a device (one-card rehearsal) or librccl is missing,
+ * by a host-staged exchange inside the process.  The communicators of a set of contexts are created by the first call (ncclCommInitAll) and
+ * kept until one of the contexts is destroyed.  Every rank's shard is built before any rank enters a collective: a shard that fails
+ * (e.g. out of memory on one device) returns its error on all ranks; a collective that does not complete within 60 s ends the LM loop with
+ * SFMHIP_E_COMM and the communicators are dropped.  summary->preprocessor_time_s = sharding + the slowest shard's construction + plan.
+ * n_ctx = 1 is sfmhip_ba_solve. */
 int  sfmhip_ba_solve_multi(sfmhip_ctx* const* ctxs, int n_ctx, double* intrinsic4, double* ext6, int n_cam, double* pts, int n_pt,
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, int n_obs,
                            const sfm_ba_options* opts, sfm_ba_summary* summary);
+/* match_features_for_all (NView:850-871) from HOST matrices on several GPUs of one process: the pairs in n_ctx contiguous blocks, a block's
+ * images uploaded to its context only over that device's own PCIe link (a chain: a block of images + one halo image), one host thread per
+ * context, no exchange; matches[p * max_per_pair ...] / counts[p] in pair order, exactly what sfmhip_descsets_create_*_host +
+ * sfmhip_match_pairs give on one context (n_ctx = 1 is that sequence in one call).  kind: SFMHIP_DESC_L2_F32 (desc[i]: float rows,
+ * dim columns) or SFMHIP_DESC_HAMMING2_U8 (uint8 rows, dim = bytes per row); ld: row strides in elements or NULL (dense). */
+int  sfmhip_match_pairs_multi(sfmhip_ctx* const* ctxs, int n_ctx, int kind, const void* const* desc, const int32_t* rows, int dim,
+                              const size_t* ld, int n_images, const int32_t* pairs, int n_pairs,
+                              double ratio, float floor_, float mult, sfm_dmatch* matches, int max_per_pair, int32_t* counts);
+/* test hook: the next n device allocations of the context fail (SFMHIP_E_HIP) -- what an out-of-memory device looks like to its callers */
+int  sfmhip_debug_fail_allocations(sfmhip_ctx*, int n);
 /* run the LM loop to termination */
 int  sfmhip_ba_run(sfmhip_ba*, sfm_ba_summary* summary);
 /* run exactly n_iter LM iterations (tolerance checks disabled); state carries over between calls */

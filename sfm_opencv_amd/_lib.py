@@ -59,7 +59,7 @@ SYMBOLS = [
     "sfmhip_ba_get_params", "sfmhip_ba_reduced_system", "sfmhip_ba_phase_ms", "sfmhip_ba_debug_table",
     "sfmhip_estimate_normals",
     "sfmhip_rccl_available", "sfmhip_rccl_get_unique_id", "sfmhip_rccl_comm_create", "sfmhip_rccl_comm_destroy",
-    "sfmhip_ba_set_rccl", "sfmhip_rccl_allreduce_f64", "sfmhip_ba_solve_multi",
+    "sfmhip_ba_set_rccl", "sfmhip_rccl_allreduce_f64", "sfmhip_ba_solve_multi", "sfmhip_match_pairs_multi", "sfmhip_debug_fail_allocations",
 ]
 
 _lib = None
@@ -136,6 +136,8 @@ def load():
         "sfmhip_ba_set_rccl": (i32, [vp, vp, i32, i32]),
         "sfmhip_rccl_allreduce_f64": (i32, [vp, vp, vp, sz]),
         "sfmhip_ba_solve_multi": (i32, [C.POINTER(vp), i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(BAOptions), C.POINTER(BASummary)]),
+        "sfmhip_match_pairs_multi": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), vp, i32, C.POINTER(sz), i32, vp, i32, f64, f32, f32, vp, i32, vp]),
+        "sfmhip_debug_fail_allocations": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

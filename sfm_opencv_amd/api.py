@@ -396,6 +396,26 @@ def ba_solve_multi(ctxs, K4, ext, pts, obs_cam, obs_pt, obs_uv, opts=None):
     return K4, ext, pts, s.asdict()
 
 
+def match_pairs_multi(ctxs, mats, pairs, ratio=0.6, floor_=10.0, mult=5.0):
+    """sfmhip_match_pairs_multi: host matrices (float32: L2, uint8: Hamming2) matched over several contexts of this process, the pairs in
+    contiguous blocks; list of DMATCH arrays in pair order."""
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    n_pairs, n = pairs.shape[0], len(mats)
+    if n_pairs == 0:
+        return []
+    ham = np.asarray(mats[0]).dtype == np.uint8
+    arrs = [np.ascontiguousarray(m, np.uint8 if ham else np.float32) for m in mats]
+    dim = arrs[0].shape[1]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    rows = np.array([a.shape[0] for a in arrs], np.int32)
+    mpp = max(1, int(rows[pairs[:, 0]].max()))
+    out = np.empty((n_pairs, mpp), DMATCH); counts = np.zeros(n_pairs, np.int32)
+    carr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    ctxs[0]._check(ctxs[0].lib.sfmhip_match_pairs_multi(carr, len(ctxs), 2 if ham else 1, ptrs, rows.ctypes.data, dim, None, n, pairs.ctypes.data, n_pairs,
+                                                         ratio, floor_, mult, out.ctypes.data, mpp, counts.ctypes.data))
+    return [out[p, :c] for p, c in enumerate(counts.tolist())]
+
+
 def ratio_filter(idx2, dist2, ratio=0.6, floor_=10.0, mult=5.0):
     """sfmhip_ratio_filter (host C, needs no GPU): the tail of match_features, NViewReconstuct.cpp:880-908."""
     lib = _lib.load()

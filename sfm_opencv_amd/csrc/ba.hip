@@ -1091,13 +1091,18 @@ static int ba_loop(sfmhip_ba* h, int max_it, bool forced)
         if (timing) { h->pending_build = par; h->pending_iter = h->iter_parity; }
         {   // spin on the sequence number; if the stream drains without publishing (a failed launch) the query ends the wait.
             // No event behind the publishing kernel: a hipEventRecord there held the next kernel back by ~10 us.
+            // With an all-reduce hook in the iteration a peer that died leaves this stream waiting inside the collective for ever: the
+            // wait then has a deadline (60 s: a thousand times the slowest iteration measured) and ends in SFMHIP_E_COMM.
             volatile unsigned long long* flag = (volatile unsigned long long*)(h->h_scal + 15);
             unsigned spins = 0;
+            const auto t_wait = std::chrono::steady_clock::now();
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-                if ((++spins & 0xffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+                if ((++spins & 0xffff) != 0) continue;
+                if (hipStreamQuery(st) != hipErrorNotReady) {
                     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->last_error = "bundle adjustment: the step scalars were not published"; return SFMHIP_E_HIP; }
                     break;
                 }
+                if (h->ar_fn && ms_since(t_wait) > 60e3) { ctx->last_error = "bundle adjustment: a collective did not complete within 60 s (a peer rank gone?)"; return SFMHIP_E_COMM; }
             }
         }
         const double cost = h->h_scal[0], gmax = h->h_scal[1], mcc = h->h_scal[2], cand_raw = h->h_scal[3];

@@ -48,6 +48,9 @@ struct sfmhip_ctx {
     // second stream of the bundle-adjustment problems (created on first use and kept: a hipStreamCreate costs milliseconds)
     hipStream_t aux_stream = nullptr;
     int    num_cus = 256;
+    // grow-only host block for the shards' arrays of sfmhip_ba_solve_multi (fresh allocations of that size cost a page fault per 4 KB: 60 ms at C5)
+    void*  host_scratch = nullptr; size_t host_scratch_bytes = 0;
+    int    inject_alloc_failures = 0;      // sfmhip_debug_fail_allocations: the next N sfm_pool_get calls fail (tests of the error paths)
     // optional per-kernel timing of the matching path (sfmhip_set_kernel_timing): event triples
     // [before kNN kernel, after it, after merge / re-score] for up to TIMING_SLOTS calls since the last query
     static constexpr int TIMING_SLOTS = 64;
@@ -163,6 +166,8 @@ void sfm_parallel(sfmhip_ctx* ctx, const std::function<void(int, int)>& f);
 int  sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out);
 void sfm_pool_put(sfmhip_ctx* ctx, void* p);
 void sfm_pool_trim(sfmhip_ctx* ctx);
+// rccl.hip: communicators cached for sets of contexts go when one of their contexts does
+void sfm_rccl_forget_ctx(sfmhip_ctx* ctx);
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int x, int m) { return (x + m - 1) / m; }

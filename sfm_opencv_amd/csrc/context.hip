@@ -114,6 +114,7 @@ int sfm_upload(sfmhip_ctx* ctx, void* dst, const void* src, size_t bytes)
 
 int sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out)
 {
+    if (ctx->inject_alloc_failures > 0) { --ctx->inject_alloc_failures; ctx->last_error = "injected allocation failure (sfmhip_debug_fail_allocations)"; return SFMHIP_E_HIP; }
     if (bytes == 0) bytes = 256;
     int best = -1;
     const size_t hi = std::max(4 * bytes, (size_t)1 << 20);
@@ -127,7 +128,15 @@ int sfm_pool_get(sfmhip_ctx* ctx, size_t bytes, void** out)
         return SFMHIP_OK;
     }
     void* q = nullptr;
-    SFM_HIP_TRY(ctx, hipMalloc(&q, bytes));
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipErrorOutOfMemory && ctx->pool_idle_bytes > 0) {
+        // idle blocks of other sizes may be all that stands between this request and success (they are only handed out for requests of
+        // 1x .. 4x their size): give them back to the driver and try once more
+        (void)hipGetLastError();
+        sfm_pool_trim(ctx);
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ctx->last_error = std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e); return SFMHIP_E_HIP; }
     ctx->pool.push_back({ q, bytes, true });
     *out = q;
     return SFMHIP_OK;
@@ -184,17 +193,27 @@ void sfmhip_destroy(sfmhip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    sfm_rccl_forget_ctx(ctx);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
     if (ctx->d_flagpool) (void)hipFree(ctx->d_flagpool);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    free(ctx->host_scratch);
     delete ctx->copy_pool;
     for (int b = 0; b < 2; ++b) { if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]); if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]); }
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     for (auto& t : ctx->tev) for (auto& e : t) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+// test hook: the next n device allocations of this context fail (what an out-of-memory shard looks like to its callers)
+int sfmhip_debug_fail_allocations(sfmhip_ctx* ctx, int n)
+{
+    if (!ctx || n < 0) return SFMHIP_E_ARG;
+    ctx->inject_alloc_failures = n;
+    return SFMHIP_OK;
 }
 
 int sfmhip_trim(sfmhip_ctx* ctx)

@@ -58,8 +58,10 @@ inline sfmhip_ctx* context(int device = 0)
     return ctx;
 }
 
-// Devices bundle_adjustment() spreads its points over (one context each; the reduced-system sums go over RCCL inside the library,
-// sfmhip_ba_solve_multi).  Default: the one context above.  Listing a device twice gives two contexts on it: the one-card rehearsal.
+// Devices match_features_for_all() spreads its image pairs over (sfmhip_match_pairs_multi: contiguous blocks of the chain, every block
+// uploaded over its own device's PCIe link, no exchange) and bundle_adjustment() its points (one context each; the reduced-system
+// sums go over RCCL inside the library, sfmhip_ba_solve_multi).  Default: the one context above.  Listing a device twice gives two
+// contexts on it: the one-card rehearsal.
 inline std::vector<sfmhip_ctx*>& ba_contexts()
 {
     static std::vector<sfmhip_ctx*> v;
@@ -116,6 +118,24 @@ inline void match_features_for_all(const std::vector<Mat>& descriptor_for_all, s
         const Mat& d = descriptor_for_all[i];
         max_rows = d.rows > max_rows ? d.rows : max_rows;
         uniform = uniform && d.type == descriptor_for_all[0].type && d.cols == descriptor_for_all[0].cols && d.cols > 0;
+    }
+    if (uniform && ba_contexts().size() > 1) {
+        // several devices (--gpus=): the chain in contiguous blocks over the contexts, host matrices straight into the one call
+        std::vector<int32_t> rows((size_t)n), pairs, counts((size_t)n - 1, 0);
+        std::vector<const void*> ptrs((size_t)n);
+        for (int i = 0; i < n; ++i) { rows[i] = descriptor_for_all[i].rows; ptrs[i] = descriptor_for_all[i].buf.data(); }
+        for (int i = 0; i + 1 < n; ++i) { printf("Matching images %d - %d\n", i, i + 1); pairs.push_back(i); pairs.push_back(i + 1); }
+        std::vector<DMatch> out((size_t)(n - 1) * max_rows);
+        const bool ham = descriptor_for_all[0].type == CV_8U;
+        rc = sfmhip_match_pairs_multi(ba_contexts().data(), (int)ba_contexts().size(), ham ? SFMHIP_DESC_HAMMING2_U8 : SFMHIP_DESC_L2_F32, ptrs.data(), rows.data(),
+                                      descriptor_for_all[0].cols, nullptr, n, pairs.data(), n - 1, 0.6, 10.0f, 5.0f,
+                                      reinterpret_cast<sfm_dmatch*>(out.data()), max_rows, counts.data());
+        if (rc != SFMHIP_OK) { printf("[Err]: match_features_for_all: %s\n", sfmhip_last_error(ctx)); return; }
+        for (int i = 0; i + 1 < n; ++i) {
+            matches_for_all.emplace_back(out.begin() + (size_t)i * max_rows, out.begin() + (size_t)i * max_rows + counts[i]);
+            if (counts[i] == 0) printf("[Warning]: zero matches between %d and %d.\n", i, i + 1);
+        }
+        return;
     }
     if (uniform) {
         std::vector<int32_t> rows((size_t)n);

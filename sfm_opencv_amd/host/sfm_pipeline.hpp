@@ -380,7 +380,7 @@ inline int driver_main(int argc, char** argv, bool nview)
         else if (a.rfind("--gpus=", 0) == 0) {          // bundle adjustment over several devices of this process: --gpus=0,1,2,3
             std::vector<int> devs;
             for (size_t at = 7; at < a.size();) { size_t e = a.find(',', at); if (e == std::string::npos) e = a.size(); devs.push_back(std::atoi(a.substr(at, e - at).c_str())); at = e + 1; }
-            if (devs.empty() || !set_ba_devices(devs)) return 1;
+            if (devs.empty() || !set_ba_devices(devs)) return 1;         // (matching spreads its pairs over the same contexts)
         }
         else if (a == "--akaze") opt.akaze = true;
         else if (a == "--sift") opt.akaze = false;

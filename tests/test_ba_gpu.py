@@ -485,6 +485,47 @@ def test_single_process_multi_context_solve_matches_the_single_gpu_call(ctx, sha
     assert s["total_time_s"] > 0
 
 
+@pytest.mark.parametrize("shape,n_ctx", [((24, 4000), 2), ((120, 12000), 3), ((60, 9000), 4)])
+def test_multi_context_solve_follows_the_single_gpu_steps(ctx, shape, n_ctx):
+    """The same comparison where it is sharp: five LM steps with every tolerance switched off (so both calls take exactly five), the
+    sharded sums against the unsharded ones: 1e-9 on the cost and on every parameter (the converged comparison above cannot be
+    that tight: sums taken in another order wander along the flat directions).  Also: the time split reported by the call."""
+    sc = synth.ba_scene(*shape)
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    o = ctx.ba_options(max_num_iterations=5, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    Kr, extr, ptsr, sr = ctx.ba_solve(*args, opts=o)
+    ctxs = [api.Context(0, use_torch_stream=False) for _ in range(n_ctx)]
+    K, ext, pts, s = api.ba_solve_multi(ctxs, *args, opts=o)
+    K2, ext2, pts2, s2 = api.ba_solve_multi(ctxs, *args, opts=o)          # again on the same contexts (communicators / blocks kept)
+    for c in ctxs:
+        c.close()
+    assert sr["iterations"] == s["iterations"] == 5 and s["successful_steps"] == sr["successful_steps"]
+    assert abs(s["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+    assert _relerr(ext, extr) <= 1e-9 and _relerr(K, Kr) <= 1e-9 and _relerr(pts, ptsr) <= 1e-9
+    assert np.array_equal(ext, ext2) and np.array_equal(pts, pts2) and np.array_equal(K, K2)
+    assert s["preprocessor_time_s"] > 0 and s["minimizer_time_s"] > 0 and s["preprocessor_time_s"] + s["minimizer_time_s"] <= s["total_time_s"] * 1.001
+
+
+def test_multi_context_solve_reports_a_failed_shard_instead_of_hanging(ctx):
+    """One rank cannot build its shard (its device allocations fail: sfmhip_debug_fail_allocations): every rank leaves with an error
+    before anyone enters a collective -- the call returns SFMHIP_E_HIP naming the rank, it does not hang; the contexts stay usable."""
+    sc = synth.ba_scene(24, 4000)
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    ctxs = [api.Context(0, use_torch_stream=False) for _ in range(3)]
+    ctxs[0].trim(); ctxs[1].trim(); ctxs[2].trim()
+    for bad in (1, 0):
+        ctxs[bad].lib.sfmhip_debug_fail_allocations(ctxs[bad].h, 3)
+        with pytest.raises(api.SfmHipError) as e:
+            api.ba_solve_multi(ctxs, *args)
+        assert "injected allocation failure" in str(e.value) and (bad == 0 or "rank 1" in str(e.value))
+        ctxs[bad].lib.sfmhip_debug_fail_allocations(ctxs[bad].h, 0)
+    K, ext, pts, s = api.ba_solve_multi(ctxs, *args)
+    Kr, extr, ptsr, sr = ctx.ba_solve(*args)
+    for c in ctxs:
+        c.close()
+    assert s["iterations"] == sr["iterations"] and abs(s["final_cost"] - sr["final_cost"]) <= 1e-7 * sr["final_cost"]
+
+
 def test_problem_memory_is_reused_across_solves_and_trim_releases_it(ctx):
     """The context keeps the device blocks of destroyed problems (a hipFree of gigabytes stalls the following calls); reuse and
     sfmhip_trim must not change results: the same solve three times, trimming in between, bit for bit."""

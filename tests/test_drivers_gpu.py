@@ -276,3 +276,6 @@ def test_nview_driver_spreads_bundle_adjustment_over_contexts(drivers, tmp_path)
     assert abs(f1 - f2) <= 1e-4 * f1, (f1, f2)
     y1 = formats.read_structure_yml(a / "structure_ba.yml"); y2 = formats.read_structure_yml(b / "structure_ba.yml")
     assert y1["points"].shape == y2["points"].shape and np.abs(y1["points"] - y2["points"]).max() <= 1e-3 * max(1.0, np.abs(y1["points"]).max())
+    # match_features_for_all spreads the chain's pairs over the same two contexts (sfmhip_match_pairs_multi): the lists, hence everything
+    # written before bundle adjustment, are the single-context ones byte for byte
+    assert (a / "structure.yml").read_bytes() == (b / "structure.yml").read_bytes()

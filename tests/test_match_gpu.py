@@ -336,3 +336,31 @@ def test_batched_host_sets_match_like_per_image_sets(ctx):
     for g, w in zip(ctx.match_pairs(hb, hp, ratio=0.97), ctx.match_pairs(hs, hp, ratio=0.97)):
         assert np.array_equal(g, w)
     assert ctx.descsets_host([]) == []
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3])
+def test_match_pairs_over_several_contexts(ctx, n_ctx):
+    """sfmhip_match_pairs_multi: the chain's pairs in contiguous blocks over n contexts (all on the box's one card here: what differs
+    from a node is only which PCIe link a block's images cross), a block's images + its halo image uploaded to its context only;
+    the lists are the single-context ones, in pair order.  Ragged image sizes, both norms, a pair list that is not a chain."""
+    rng = np.random.default_rng(5)
+    chain = [c.copy() for c in synth.sift_descriptor_chain(7, 600, seed=9)]
+    chain[1] = chain[1][:411]; chain[5] = chain[5][:64]
+    pairs = np.stack([np.arange(6), np.arange(1, 7)], 1)
+    ctxs = [api.Context(0, use_torch_stream=False) for _ in range(n_ctx)]
+    want = api.match_features_for_all(chain, ctx=ctx)
+    got = api.match_pairs_multi(ctxs, chain, pairs)
+    assert len(got) == 6 and sum(len(g) for g in got) > 200
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    odd_pairs = np.array([[6, 0], [2, 5], [3, 3], [0, 1], [4, 2]])
+    sets = ctx.descsets_host(chain)
+    for g, w in zip(api.match_pairs_multi(ctxs, chain, odd_pairs), ctx.match_pairs(sets, odd_pairs)):
+        assert np.array_equal(g, w)
+    ham = [rng.integers(0, 256, (r, 61), dtype=np.uint8) for r in (300, 211, 64, 500, 77)]
+    hp = np.stack([np.arange(4), np.arange(1, 5)], 1)
+    hs = ctx.descsets_host(ham)
+    for g, w in zip(api.match_pairs_multi(ctxs, ham, hp, ratio=0.97), ctx.match_pairs(hs, hp, ratio=0.97)):
+        assert np.array_equal(g, w)
+    for c in ctxs:
+        c.close()
