@@ -97,6 +97,20 @@ __global__ __launch_bounds__(256) void tile1(float* p, int rows, int cols, size_
     const int row = blockIdx.y * ROWS + threadIdx.x / TPR, col = (blockIdx.x * TPR + threadIdx.x % TPR) * 4;
     if (row < rows && col + 3 < cols) { v4f v = { 1.f, 2.f, 3.f, (float)col }; *(v4f*)(p + (size_t)row * ld + col) = v; }
 }
+// round 4: short-and-wide workgroup tiles under the XCD-banded mapping (one XCD walks along a band of ROWS rows): ROWS rows x SEGF floats
+// per workgroup, consecutive threads along a row (16-byte stores), a wave covering 1 KB of one row per instruction
+template <int ROWS, int SEGF>
+__global__ __launch_bounds__(256) void tile_band(float* p, int rows, int cols, size_t ld, int nqb, int ntb)
+{
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int qb = (slot / ntb) * 8 + xcd, tb = slot % ntb;
+    if (qb >= nqb) return;
+    constexpr int TPR = SEGF / 4;                    // threads (16 B each) per row segment
+    for (int e = threadIdx.x; e < ROWS * TPR; e += 256) {
+        const int row = qb * ROWS + e / TPR, col = tb * SEGF + (e % TPR) * 4;
+        if (row < rows && col + 3 < cols) { v4f v = { 1.f, 2.f, 3.f, (float)col }; *(v4f*)(p + (size_t)row * ld + col) = v; }
+    }
+}
 int main(int argc, char** argv)
 {
     if (argc > 1) {
@@ -127,6 +141,9 @@ int main(int argc, char** argv)
             run("tile 128x128 row-parity 8 rows x 128 B, ld 10000", [&] { hipLaunchKernelGGL((tile_par<8>), dim3(80 * 80), dim3(256), 0, 0, p, 10000, 10000, (size_t)10000, 80, 80); });
             run("tile 128x10000 row bands 1 row x 1 KB, ld 10000", [&] { hipLaunchKernelGGL((tile<1, 10000>), dim3(79, 1), dim3(256), 0, 0, p, 10000, 10000, (size_t)10000); });
             run("row1 grid 2048, ld 10000", [&] { hipLaunchKernelGGL(row1, dim3(2048), dim3(256), 0, 0, p, 10000, 10000, (size_t)10000); });
+#define BAND(R, F) do { const int nqb = (10000 + R - 1) / R, ntb = (10000 + F - 1) / F; \
+            run("band tile " #R " rows x " #F " floats, XCD-banded, ld 10000", [&] { hipLaunchKernelGGL((tile_band<R, F>), dim3(((nqb + 7) / 8) * 8 * ntb), dim3(256), 0, 0, p, 10000, 10000, (size_t)10000, nqb, ntb); }); } while (0)
+            BAND(128, 128); BAND(64, 256); BAND(32, 512); BAND(16, 1024); BAND(8, 2048); BAND(32, 1024); BAND(16, 2048); BAND(4, 4096); BAND(32, 128); BAND(64, 128);
         }
         return 0;
     }

@@ -277,8 +277,9 @@ template <typename T>
 static int dupload(sfmhip_ba* h, T** p, const T* src, size_t count)
 {
     int rc = dalloc(h, p, count); if (rc) return rc;
-    if (count) SFM_HIP_TRY(h->ctx, hipMemcpyAsync(*p, src, count * sizeof(T), hipMemcpyHostToDevice, h->ctx->stream));
-    return SFMHIP_OK;
+    // through the pinned staging ring: the source (often a function-local vector) has been consumed when this returns -- a
+    // hipMemcpyAsync from pageable memory does not promise that
+    return count ? sfm_upload(h->ctx, *p, src, count * sizeof(T)) : SFMHIP_OK;
 }
 
 static BADev make_dev(const sfmhip_ba* h, double radius, bool at_candidate = false)
@@ -1226,12 +1227,15 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     hipLaunchKernelGGL(setup_max_kernel, dim3((unsigned)std::min(1024, (int)gpt)), dim3(256), 0, st, (const su32*)st_pt, np, (su32*)(d_flags + 1));
     int flags[4] = { 0, 0, 0, 0 };
     stamp("observation sort");
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
     // behind the sort on the stream: the pixels and the points (the host fills the pinned staging buffers meanwhile)
     TRY_RC(sfm_upload(ctx, d_ruv, obs_uv, 2 * (size_t)nobs * sizeof(double)));
     TRY_RC(sfm_upload(ctx, d_rpts, pts, 3 * (size_t)np * sizeof(double)));
     stamp("pixels + points uploaded");
-    SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // (no early return between this copy into a stack array and the synchronisation behind it)
+    {
+        const hipError_t e1 = hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st), e2 = hipStreamSynchronize(st);
+        SFM_HIP_TRY(ctx, e1); SFM_HIP_TRY(ctx, e2);
+    }
     if (flags[0]) { ctx->last_error = "bad argument: observation with a camera or point index out of range"; return SFMHIP_E_ARG; }
     h->setup_ms[0] = ms_since(t0);
     // ---- points by camera list: LSD over groups of list positions, last group first
@@ -1272,11 +1276,12 @@ static int ba_build_orderings(sfmhip_ba* h, const double* pts, const int32_t* ob
     su32* npair = nullptr;
     TRY_RC(T.get(&npair, (size_t)np + 1));
     SFM_HIP_TRY(ctx, hipMemsetAsync(npair, 0, ((size_t)np + 1) * sizeof(su32), st));
-    if (np) hipLaunchKernelGGL(setup_pair_count_kernel, dim3(gpt), dim3(256), 0, st, (const int*)h->d_pt_start, (const int*)h->d_ocam, np, h->fix0, npair);
+    SFM_HIP_TRY(ctx, hipMemsetAsync(d_total + 1, 0, sizeof(su64), st));
+    if (np) hipLaunchKernelGGL(setup_pair_count_kernel, dim3(gpt), dim3(256), 0, st, (const int*)h->d_pt_start, (const int*)h->d_ocam, np, h->fix0, npair, d_total + 1);
     setup_enqueue_scan(st, npair, (size_t)np + 1, bsum, d_total);
     su64 total_pairs = 0;
     std::vector<int> cam_start((size_t)nc + 1);
-    SFM_HIP_TRY(ctx, hipMemcpyAsync(&total_pairs, d_total, sizeof(su64), hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(ctx, hipMemcpyAsync(&total_pairs, d_total + 1, sizeof(su64), hipMemcpyDeviceToHost, st));      // the count kernel's own 64-bit sum: the scan's counters may have wrapped
     SFM_HIP_TRY(ctx, hipMemcpyAsync(cam_start.data(), h->d_cam_start, cam_start.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(ctx, hipStreamSynchronize(st));
     SFM_HIP_TRY(ctx, hipGetLastError());

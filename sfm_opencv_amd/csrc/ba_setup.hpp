@@ -308,14 +308,27 @@ __device__ __forceinline__ int setup_lead_fixed(const int* __restrict__ ocam, in
     if (fix0) while (lo + z < hi && ocam[lo + z] == 0) ++z;
     return z;
 }
-__global__ __launch_bounds__(256) void setup_pair_count_kernel(const int* __restrict__ pt_start, const int* __restrict__ ocam, int np, int fix0, su32* __restrict__ npair)
+// total64 (zeroed by the caller): the number of pairs in 64 bits.  The per-point counters and the tile sums of the scan behind them are
+// 32 bits wide and WRAP for absurd inputs (4096 points of 1449 observations each in one tile); the caller rejects the problem on this
+// sum before it looks at anything the scan produced.
+__global__ __launch_bounds__(256) void setup_pair_count_kernel(const int* __restrict__ pt_start, const int* __restrict__ ocam, int np, int fix0, su32* __restrict__ npair,
+                                                               su64* __restrict__ total64)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= np) return;
-    const int lo = pt_start[s], hi = pt_start[s + 1];
-    const su64 m = (su64)(hi - lo - setup_lead_fixed(ocam, lo, hi, fix0));
-    const su64 c = m * (m - (m ? 1 : 0)) / 2;
-    npair[s] = c > 0xffffffffull ? 0xffffffffu : (su32)c;       // saturates; the 64-bit total then exceeds the caller's limit
+    su64 c = 0;
+    if (s < np) {
+        const int lo = pt_start[s], hi = pt_start[s + 1];
+        const su64 m = (su64)(hi - lo - setup_lead_fixed(ocam, lo, hi, fix0));
+        c = m * (m - (m ? 1 : 0)) / 2;
+        npair[s] = c > 0xffffffffull ? 0xffffffffu : (su32)c;
+    }
+    su64 v = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
+        v += ((su64)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long*)total64, (unsigned long long)v);
 }
 
 // thread per observation i: its pairs (i, j > i) in the order "for i, for j" of the point -- key = ca * nc + cb with ca >= cb,

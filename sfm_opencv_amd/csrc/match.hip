@@ -1053,6 +1053,13 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
 
     // merge across the 32 lanes that share a query row (as knn2_i8_kernel), one query tile at a time, on integer keys
     // K = key + 192 cells = 256 distance + tile for a real train (< 2^16); a pad row or the initial value is above 2^20
+    // The margin between the two, spelled out (advisor, round 3): the largest real key is 256 * (4 * H4_MAX_NBYTES) + 255 = 62,719;
+    // a pad row's spare values (6.0 on both sides, the train side's last K-step under a 2^8 block scale) put its key above 3e6 (see the
+    // kernel's header); block 23's 23 + 4 products alone give 27 * 36 * 2^10 = 995,328.  Change H4_ROW_BYTES, the number of spare values
+    // or the 2^8 scale and the k_pad = 2^20 test below no longer separates the two: the asserts pin the ingredients, and
+    // tests/test_match_gpu.py::test_knn2_hamming2_matrix_core_kernel_pad_rows_never_beat_the_worst_real_row the outcome.
+    static_assert(256 * (4 * H4_MAX_NBYTES) + 255 < (1 << 16), "real Hamming2 keys must stay below 2^16");
+    static_assert(27 * 36 * 1024 + 768 >= (1 << 20) - (1 << 16), "pad-row keys must clear every real key by the tested margin");
     const int off_k = 768 * pd.dim, k_pad = 1 << 20;
     const int win_base = t_begin & ~8191;
     int2* wk = (int2*)lds + wave * (32 * 33);

@@ -319,3 +319,17 @@ def test_normals_at_300k_points(ctx):
     radial = -(pts - np.array([0.3, -0.2, 0.1])) / np.linalg.norm(pts - np.array([0.3, -0.2, 0.1]), axis=1, keepdims=True)
     cosang = (nrm * radial).sum(1)
     assert np.quantile(cosang, 0.01) > 0.95
+
+
+def test_c3_on_the_bench_own_generator_follows_the_oracle(ctx):
+    """bench.py times the std::mt19937_64 scenes of host/sfm_synth.cpp, the tests above the numpy PCG64 ones: the benchmarked inputs
+    themselves under parity (round-3 review): C3 = 50 cameras / 80,000 points, six forced LM steps against the oracle, 1e-8 on the cost."""
+    sc = synth.ba_scene_mt(50, 80000)
+    args = (sc["K0"], sc["ext0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"])
+    pb = ctx.ba_create(*args)
+    sg = pb.iterate(6)
+    pb.close()
+    so = orc.ba_solve(*args, force_iterations=6)[3]
+    assert sg["iterations"] == so["iterations"] == 6 and sg["successful_steps"] == so["successful_steps"]
+    assert abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-10 * so["initial_cost"]
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"], (sg["final_cost"], so["final_cost"])

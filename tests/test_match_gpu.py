@@ -141,6 +141,19 @@ def test_knn2_hamming2_matrix_core_kernel_ties_and_extremes(ctx):
     assert np.array_equal(i4, oi) and np.array_equal(d4, od) and d4.max() == 244.0
 
 
+@pytest.mark.parametrize("nt", [1, 2, 31, 33, 45, 100, 257])
+def test_knn2_hamming2_matrix_core_kernel_pad_rows_never_beat_the_worst_real_row(ctx, nt):
+    """The margin between real rows and the rows that pad a set to whole tiles (advisor, round 3): train counts that are not
+    multiples of 32, EVERY real distance at the maximum 4 * 61 = 244 -- the neighbours must still be real rows 0 and 1 (lowest
+    indices on the tie), on the matrix-core kernel as on the VALU one."""
+    q = np.zeros((70, 61), np.uint8); t = np.full((nt, 61), 0x55, np.uint8)
+    for path in (4, 3):
+        i, d = _knn2_hamming_dev(ctx, q, t, path)
+        oi, od = orc.knn2_hamming2(q, t)
+        assert np.array_equal(i, oi) and np.array_equal(d.view(np.uint32), od.view(np.uint32)), path
+        assert (i[:, 0] == 0).all() and (d[:, 0] == 244.0).all() and (i[:, 1] == (1 if nt > 1 else -1)).all()
+
+
 def test_knn2_hamming2_forced_paths_are_checked(ctx):
     import torch
     t64 = ctx.descset_hamming2(torch.zeros((10, 64), dtype=torch.uint8, device="cuda"))
