@@ -461,9 +461,15 @@ def match_features_for_all(descriptor_for_all, ctx=None):
     n = len(descriptor_for_all)
     if n < 2:
         return []
-    sets = ctx.descsets_host(descriptor_for_all)          # one call: one pass of the staging threads, one transfer stream, one preparation launch
     pairs = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
-    out = ctx.match_pairs(sets, pairs)
+    mats = [np.asarray(d) for d in descriptor_for_all]
+    if len({(m.dtype, m.shape[1]) for m in mats}) == 1 and mats[0].dtype in (np.float32, np.uint8):
+        # ONE C call for the whole chain (sfmhip_match_pairs_multi on this context: sets created from the host matrices in one pass of
+        # the staging threads, one preparation launch, one batched kNN-2 + ratio tail, sets released)
+        out = match_pairs_multi([ctx], mats, pairs)
+    else:
+        sets = ctx.descsets_host(mats)
+        out = ctx.match_pairs(sets, pairs)
     for i, m in enumerate(out):
         if len(m) == 0:
             print("[Warning]: zero matches between %d and %d." % (i, i + 1))
