@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
     constexpr int NG = 12 * (TROWS / 32);                    // K-steps per stage
 #if !defined(H4_EXP) || !defined(SFMHIP_EXPERIMENTS)
 #undef H4_EXP
-#define H4_EXP 0               // timing experiments only (SFMHIP_EXPERIMENTS builds; wrong results): 1 = no staging after the first stage, 2 = no barriers, 4 = no top-2 updates, 8 = no fragment reads after the first three
+#define H4_EXP 0               // timing experiments only (SFMHIP_EXPERIMENTS builds; wrong results): 1 = no staging after the first stage, 2 = no barriers, 4 = no top-2 updates, 8 = no fragment reads after the first three, 32 = one stage per workgroup, 64 = no merge epilogue, 128 = no query loads
 #endif
 
     constexpr int PASSES = BUF_BYTES / (1024 * NW);          // LDS-DMA instructions per wave and stage: 6 (4 waves) / 3 (8 waves)
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
     const gbytes T = (gbytes)(uintptr_t)pd.t;
     const int t_begin = chunk * pd.chunk_rows;
     int t_end = t_begin + pd.chunk_rows; if (t_end > pd.nt_pad) t_end = pd.nt_pad;
-    const int nblocks = (t_end - t_begin) / TROWS;
+    const int nblocks = (H4_EXP & 32) ? 1 : (t_end - t_begin) / TROWS;        // 32: one stage only (what a workgroup costs before and after its loop)
     const int q0 = qb * QB + wave * 64;
     // sets are padded to 256 rows: with 512-row query blocks the upper waves of the last block may have no rows; they still stage and
     // meet the barriers, on the block's first rows, and write nothing
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
     for (int at = 0; at < 2; ++at)
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
-            v4i a = *(gv4)(Q + (size_t)(q0r + 32 * at + l31) * RB + 16 * (2 * s + half));
+            v4i a = (H4_EXP & 128) ? (v4i){ lane, s, at, 7 } : *(gv4)(Q + (size_t)(q0r + 32 * at + l31) * RB + 16 * (2 * s + half));       // 128: no query loads
             a ^= (v4i){ (int)0x88888888, (int)0x88888888, (int)0x88888888, (int)0x88888888 };
             if (s == 11) {
                 if (half == 0) a[3] = (a[3] & 0x0000ffff) | 0x77770000;                                  // values 732..735: 6.0
@@ -1062,6 +1062,15 @@ __global__ __launch_bounds__(64 * NW, 2) void knn2_hamming2_fp4_kernel(const Pai
     static_assert(27 * 36 * 1024 + 768 >= (1 << 20) - (1 << 16), "pad-row keys must clear every real key by the tested margin");
     const int off_k = 768 * pd.dim, k_pad = 1 << 20;
     const int win_base = t_begin & ~8191;
+    if (H4_EXP & 64) {            // 64: no merge (one store per lane keeps the registers alive)
+        float sum = 0.0f;
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += best1[at][i] + best2[at][i];
+        if (sum == 12345.0f) part[2 * pd.part_off + tid] = 1;
+        return;
+    }
     int2* wk = (int2*)lds + wave * (32 * 33);
 #pragma unroll
     for (int at = 0; at < 2; ++at) {
